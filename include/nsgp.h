@@ -1,0 +1,251 @@
+/* nsgp.h -- C ABI of libnsgp_hip.so: the MI355X (gfx950) device kernels behind the
+ * non-stationary GP / DSVI deep-GP hot path of Stansfash/nonstationary-precip.
+ *
+ * The reference is pure Python over gpytorch/torch and has no FFI of its own; each entry point
+ * below names the reference arithmetic it replaces (paths relative to /root/reference) and is
+ * what a maintainer of the reference would bind with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (hipMalloc / torch caching allocator) unless it says host;
+ *  - matrices are row-major with an explicit leading dimension (elements, not bytes);
+ *  - `stream` is a hipStream_t passed as void*; all functions are asynchronous and stream-ordered,
+ *    never allocate, never synchronise; the caller owns every buffer, including workspaces whose
+ *    size the matching *_workspace() function returns (bytes);
+ *  - return 0 on success, -k when argument k (1-based) is invalid, >0 = hipError_t of the launch;
+ *  - functions are re-entrant (no global mutable state);
+ *  - suffix _f32 / _f64 is the arithmetic type the kernel computes in.
+ */
+#ifndef NSGP_H
+#define NSGP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NSGP_MAX_DIM 8          /* input dimension D supported by the pairwise kernels */
+
+/* library / device identification (host) */
+int nsgp_abi_version(void);                 /* bumps when a signature changes */
+const char* nsgp_build_arch(void);          /* "gfx950" */
+
+/* ------------------------------------------------------------------------------------------
+ * K1  Diagonal Gibbs kernel (Rasmussen & Williams eq. 4.32)
+ *     K[i,j] = os * prod_d sqrt(2 l1[d,i] l2[d,j] / (l1[d,i]^2 + l2[d,j]^2))
+ *                 * exp(-sum_d (x1[i,d]-x2[j,d])^2 / (l1[d,i]^2 + l2[d,j]^2))  (+ diag_add on i==j)
+ *     replaces models/gibbs_kernels.py:154-162 (GibbsKernel.forward; 8 full-size temporaries)
+ *     and the ScaleKernel multiply of GibbsSafeScaleKernel (:164-168).
+ *     x1:(n1,D) x2:(n2,D) row-major contiguous; ell1:(D,n1) ell2:(D,n2) dim-major contiguous.
+ *     outputscale, diag_add: device scalars (1 element; NULL = 1 and 0) so trainable
+ *     hyper-parameters (raw_outputscale, likelihood noise) never round-trip through the host.
+ * ------------------------------------------------------------------------------------------ */
+int nsgp_gibbs_build_fwd_f32(const float* x1, const float* x2, const float* ell1, const float* ell2,
+                             int64_t n1, int64_t n2, int D, const float* outputscale, const float* diag_add,
+                             float* K, int64_t ldk, void* stream);
+int nsgp_gibbs_build_fwd_f64(const double* x1, const double* x2, const double* ell1, const double* ell2,
+                             int64_t n1, int64_t n2, int D, const double* outputscale, const double* diag_add,
+                             double* K, int64_t ldk, void* stream);
+/* backward: G = dLoss/dK (n1,n2).  Outputs (any may be NULL): g_ell1:(D,n1) g_ell2:(D,n2)
+ * g_x1:(n1,D) g_x2:(n2,D) g_os:(1).  Deterministic two-pass reduction (no atomics). */
+size_t nsgp_gibbs_build_bwd_workspace(int64_t n1, int64_t n2, int D, int elem_size);
+int nsgp_gibbs_build_bwd_f32(const float* x1, const float* x2, const float* ell1, const float* ell2,
+                             int64_t n1, int64_t n2, int D, const float* outputscale,
+                             const float* G, int64_t ldg,
+                             float* g_ell1, float* g_ell2, float* g_x1, float* g_x2, float* g_os,
+                             void* ws, size_t ws_bytes, void* stream);
+int nsgp_gibbs_build_bwd_f64(const double* x1, const double* x2, const double* ell1, const double* ell2,
+                             int64_t n1, int64_t n2, int D, const double* outputscale,
+                             const double* G, int64_t ldg,
+                             double* g_ell1, double* g_ell2, double* g_x1, double* g_x2, double* g_os,
+                             void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K2  Batched RBF-ARD kernel  K[b,i,j] = os[b] * exp(-0.5 sum_d ((x1[b,i,d]-x2[b,j,d])/ls[b,d])^2)
+ *     replaces gpytorch ScaleKernel(RBFKernel(ard)) as built at models/dgps.py:44-46 and
+ *     models/gibbs_kernels.py:67-69.  x1:(batch,n1,D) with batch stride sx1 (0 = shared),
+ *     ls:(batch,D), os:(batch) device arrays (parameters stay on the device).
+ * ------------------------------------------------------------------------------------------ */
+int nsgp_rbf_build_fwd_f32(const float* x1, const float* x2, const float* ls, const float* os,
+                           int64_t batch, int64_t n1, int64_t n2, int D, int64_t sx1, int64_t sx2,
+                           float diag_add, float* K, int64_t ldk, int64_t sK, void* stream);
+int nsgp_rbf_build_fwd_f64(const double* x1, const double* x2, const double* ls, const double* os,
+                           int64_t batch, int64_t n1, int64_t n2, int D, int64_t sx1, int64_t sx2,
+                           double diag_add, double* K, int64_t ldk, int64_t sK, void* stream);
+/* backward: outputs (any may be NULL) g_x1:(batch,n1,D) g_x2:(batch,n2,D) g_ls:(batch,D) g_os:(batch) */
+size_t nsgp_rbf_build_bwd_workspace(int64_t batch, int64_t n1, int64_t n2, int D, int elem_size);
+int nsgp_rbf_build_bwd_f32(const float* x1, const float* x2, const float* ls, const float* os,
+                           int64_t batch, int64_t n1, int64_t n2, int D, int64_t sx1, int64_t sx2,
+                           const float* G, int64_t ldg, int64_t sG,
+                           float* g_x1, float* g_x2, float* g_ls, float* g_os,
+                           void* ws, size_t ws_bytes, void* stream);
+int nsgp_rbf_build_bwd_f64(const double* x1, const double* x2, const double* ls, const double* os,
+                           int64_t batch, int64_t n1, int64_t n2, int D, int64_t sx1, int64_t sx2,
+                           const double* G, int64_t ldg, int64_t sG,
+                           double* g_x1, double* g_x2, double* g_ls, double* g_os,
+                           void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K3  Paciorek-Schervish kernel, D = 2, closed-form 2x2 determinants / inverse
+ *     K[i,j] = |S1_i|^(1/4) |S2_j|^(1/4) |(S1_i+S2_j)/2|^(-1/2)
+ *              * exp(-d^T ((S1_i+S2_j)/2 + jitter I)^-1 d),   d = x1_i - x2_j
+ *     replaces models/multivariate_gibbs_kernel.py:98-150 and
+ *     models/sparse_multivariate_gibbs_kernel.py:103-154 ((N,N,2,2) temporaries, det/inverse).
+ *     sig1:(n1,4) sig2:(n2,4) row-major 2x2 per point.
+ * ------------------------------------------------------------------------------------------ */
+int nsgp_ps2d_build_fwd_f32(const float* x1, const float* x2, const float* sig1, const float* sig2,
+                            int64_t n1, int64_t n2, float jitter, float* K, int64_t ldk, void* stream);
+int nsgp_ps2d_build_fwd_f64(const double* x1, const double* x2, const double* sig1, const double* sig2,
+                            int64_t n1, int64_t n2, double jitter, double* K, int64_t ldk, void* stream);
+/* backward wrt the per-point matrices: g_sig1:(n1,4) g_sig2:(n2,4) (either may be NULL) */
+size_t nsgp_ps2d_build_bwd_workspace(int64_t n1, int64_t n2, int elem_size);
+int nsgp_ps2d_build_bwd_f32(const float* x1, const float* x2, const float* sig1, const float* sig2,
+                            int64_t n1, int64_t n2, float jitter, const float* G, int64_t ldg,
+                            float* g_sig1, float* g_sig2, void* ws, size_t ws_bytes, void* stream);
+int nsgp_ps2d_build_bwd_f64(const double* x1, const double* x2, const double* sig1, const double* sig2,
+                            int64_t n1, int64_t n2, double jitter, const double* G, int64_t ldg,
+                            double* g_sig1, double* g_sig2, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense contraction on the matrix cores (v_mfma_f32_32x32x2_f32 / v_mfma_f64_16x16x4_f64)
+ *     C[b] = alpha * op(A[b]) * op(B[b]) + beta * C[b]        (M x N, inner K)
+ *     replaces the torch matmul / triangular_solve / inverse chains of
+ *     models/gibbs_kernels.py:203,225 (K_xz Kzz^-1/2), models/nonstationary_models.py:55-58,142-150
+ *     and gpytorch VariationalStrategy's  L^-1 Kzx,  (S - I) A  (SURVEY A.3).
+ *     A element (m,k) at A[m*sam + k*sak], B element (k,n) at B[k*sbk + n*sbn] (one stride of each
+ *     pair must be 1), C row-major with ldc.  Two-level batch: b = b1*nb2 + b2, offsets
+ *     b1*s?1 + b2*s?2 (elements).
+ *     flags: triangular structure that lets whole K-tiles / output tiles be skipped and masks the
+ *     other triangle of the operand (so an un-zeroed triangle is never read as data).
+ * ------------------------------------------------------------------------------------------ */
+#define NSGP_GEMM_A_LOWER   1   /* op(A)(m,k) == 0 for k > m  */
+#define NSGP_GEMM_A_UPPER   2   /* op(A)(m,k) == 0 for k < m  */
+#define NSGP_GEMM_B_LOWER   4   /* op(B)(k,n) == 0 for n > k  */
+#define NSGP_GEMM_B_UPPER   8   /* op(B)(k,n) == 0 for n < k  */
+#define NSGP_GEMM_C_LOWER  16   /* only the lower triangle (n <= m) of C is computed/stored; the
+                                   strict upper triangle is written as zero when beta == 0 */
+#define NSGP_GEMM_NO_SPLITK 32  /* never split the inner dimension (no workspace needed) */
+size_t nsgp_gemm_workspace(int64_t M, int64_t N, int64_t K, int64_t nb1, int64_t nb2, int elem_size);
+int nsgp_gemm_f32(int64_t M, int64_t N, int64_t K, float alpha,
+                  const float* A, int64_t sam, int64_t sak, int64_t sa1, int64_t sa2,
+                  const float* B, int64_t sbk, int64_t sbn, int64_t sb1, int64_t sb2,
+                  float beta, float* C, int64_t ldc, int64_t sc1, int64_t sc2,
+                  int64_t nb1, int64_t nb2, int flags, void* ws, size_t ws_bytes, void* stream);
+int nsgp_gemm_f64(int64_t M, int64_t N, int64_t K, double alpha,
+                  const double* A, int64_t sam, int64_t sak, int64_t sa1, int64_t sa2,
+                  const double* B, int64_t sbk, int64_t sbn, int64_t sb1, int64_t sb2,
+                  double beta, double* C, int64_t ldc, int64_t sc1, int64_t sc2,
+                  int64_t nb1, int64_t nb2, int flags, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K4  Blocked right-looking Cholesky A = L L^T (lower, in place, strict upper zeroed), batched.
+ *     Panel: LDS-resident 64x64 diagonal factor + explicit inverse; trailing update on MFMA.
+ *     replaces psd_safe_cholesky (models/gibbs_kernels.py:201,298), gpytorch
+ *     VariationalStrategy._cholesky_factor and the Cholesky inside ExactMarginalLogLikelihood /
+ *     MultivariateNormal.log_prob, and torch.linalg.solve at utils/functional.py:33.
+ *     info:(batch) int32 device: 0 ok, k>0 = leading minor k not positive definite (LAPACK).
+ * K5  trtri: X = L^-1 (lower, out of place, strict upper zeroed), recursive on MFMA GEMMs;
+ *     replaces torch.triangular_solve(eye, chol) (models/gibbs_kernels.py:203,300) and
+ *     L.inv_matmul(Kzx) of gpytorch (as the dense product L^-1 * Kzx).
+ * ------------------------------------------------------------------------------------------ */
+size_t nsgp_potrf_workspace(int64_t n, int64_t batch, int elem_size);
+int nsgp_potrf_f32(float* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int32_t* info,
+                   void* ws, size_t ws_bytes, void* stream);
+int nsgp_potrf_f64(double* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int32_t* info,
+                   void* ws, size_t ws_bytes, void* stream);
+size_t nsgp_trtri_workspace(int64_t n, int64_t batch, int elem_size);
+int nsgp_trtri_f32(const float* L, int64_t n, int64_t ldl, int64_t sL, float* X, int64_t ldx,
+                   int64_t sX, int64_t batch, void* ws, size_t ws_bytes, void* stream);
+int nsgp_trtri_f64(const double* L, int64_t n, int64_t ldl, int64_t sL, double* X, int64_t ldx,
+                   int64_t sX, int64_t batch, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K6  SVGP epilogue (whitened VariationalStrategy.forward), per output GP b:
+ *       mean[b,j] = sum_k A[b,k,j] m[b,k]          (+ mu added by the caller)
+ *       var [b,j] = base[b] + sum_k (C[b,k,j]^2 - A[b,k,j]^2)
+ *     with A = L^-1 Kzx and C = Lq^T A, both (batch,M,n) row-major.
+ *     backward (given gmean, gvar (batch,n)); the Lq C2 term of Abar is added by a beta=1 GEMM:
+ *       Abar[b,k,j] = m[b,k] gmean[b,j] - 2 gvar[b,j] A[b,k,j]
+ *       C2  [b,k,j] = 2 gvar[b,j] C[b,k,j]          (= dLoss/dC; Lq_bar = tril(A C2^T))
+ *       mbar[b,k]   = sum_j A[b,k,j] gmean[b,j]
+ * ------------------------------------------------------------------------------------------ */
+int nsgp_svgp_colstats_f32(const float* A, const float* C, const float* m, const float* base,
+                           int64_t batch, int64_t M, int64_t n, float* mean, float* var, void* stream);
+int nsgp_svgp_colstats_f64(const double* A, const double* C, const double* m, const double* base,
+                           int64_t batch, int64_t M, int64_t n, double* mean, double* var, void* stream);
+int nsgp_svgp_colstats_bwd_f32(const float* A, const float* C, const float* m,
+                               const float* gmean, const float* gvar, int64_t batch, int64_t M, int64_t n,
+                               float* Abar, float* C2, float* mbar, void* stream);
+int nsgp_svgp_colstats_bwd_f64(const double* A, const double* C, const double* m,
+                               const double* gmean, const double* gvar, int64_t batch, int64_t M, int64_t n,
+                               double* Abar, double* C2, double* mbar, void* stream);
+
+/* DeepGPLayer sampling:  h[s,i,c] = mean[c,s?,i] + sqrt(var[c,s?,i]) * eps[s,i,c]
+ *   mean/var are (b, ns, n) with ns == 1 (deterministic first layer, broadcast over S) or ns == S.
+ *   backward accumulates gmean/gvar (b, ns, n) from gh (S,n,b). */
+int nsgp_dgp_sample_fwd_f32(const float* mean, const float* var, const float* eps, int64_t S, int64_t ns,
+                            int64_t n, int64_t b, float* h, void* stream);
+int nsgp_dgp_sample_bwd_f32(const float* var, const float* eps, const float* gh, int64_t S, int64_t ns,
+                            int64_t n, int64_t b, float* gmean, float* gvar, void* stream);
+int nsgp_dgp_sample_fwd_f64(const double* mean, const double* var, const double* eps, int64_t S, int64_t ns,
+                            int64_t n, int64_t b, double* h, void* stream);
+int nsgp_dgp_sample_bwd_f64(const double* var, const double* eps, const double* gh, int64_t S, int64_t ns,
+                            int64_t n, int64_t b, double* gmean, double* gvar, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K7  ELBO reductions.
+ *   gauss_ell: out[0] = scale * sum_{s,i} -0.5*(((y_i-mu_si)^2 + v_si)/noise + log noise + log 2pi)
+ *              (GaussianLikelihood.expected_log_prob + VariationalELBO/DeepApproximateMLL means,
+ *               experiments/deepgp_spatial_bench.py:61,84-88); noise:(1) device.
+ *              bwd writes gmu, gv (S,n) and gnoise (1) for upstream gradient gout (host scalar).
+ *   kl_whitened: out[b] = 0.5*(||Lq_b||_F^2(lower) + m_b.m_b - M - 2 sum log|diag Lq_b|)
+ *              (CholeskyVariationalDistribution vs N(0,I)); bwd writes gm, gLq (lower).
+ * ------------------------------------------------------------------------------------------ */
+size_t nsgp_reduce_workspace(int64_t n_elems, int elem_size);
+int nsgp_gauss_ell_fwd_f32(const float* y, const float* mu, const float* v, const float* noise,
+                           int64_t S, int64_t n, float scale, float* out, void* ws, size_t ws_bytes, void* stream);
+int nsgp_gauss_ell_bwd_f32(const float* y, const float* mu, const float* v, const float* noise,
+                           int64_t S, int64_t n, float scale, float gout, float* gmu, float* gv, float* gnoise,
+                           void* ws, size_t ws_bytes, void* stream);
+int nsgp_gauss_ell_fwd_f64(const double* y, const double* mu, const double* v, const double* noise,
+                           int64_t S, int64_t n, double scale, double* out, void* ws, size_t ws_bytes, void* stream);
+int nsgp_gauss_ell_bwd_f64(const double* y, const double* mu, const double* v, const double* noise,
+                           int64_t S, int64_t n, double scale, double gout, double* gmu, double* gv, double* gnoise,
+                           void* ws, size_t ws_bytes, void* stream);
+int nsgp_kl_whitened_fwd_f32(const float* m, const float* Lq, int64_t batch, int64_t M, float* out,
+                             void* ws, size_t ws_bytes, void* stream);
+int nsgp_kl_whitened_bwd_f32(const float* m, const float* Lq, int64_t batch, int64_t M, float gout,
+                             float* gm, float* gLq, void* stream);
+int nsgp_kl_whitened_fwd_f64(const double* m, const double* Lq, int64_t batch, int64_t M, double* out,
+                             void* ws, size_t ws_bytes, void* stream);
+int nsgp_kl_whitened_bwd_f64(const double* m, const double* Lq, int64_t batch, int64_t M, double gout,
+                             double* gm, double* gLq, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Small helpers on the same stream
+ * ------------------------------------------------------------------------------------------ */
+/* out = tril(P) with halved diagonal, symmetrised: S = Phi(P) + Phi(P)^T   (Cholesky backward) */
+int nsgp_chol_bwd_phi_sym_f32(const float* P, float* S, int64_t n, int64_t ld, int64_t sP, int64_t batch, void* stream);
+int nsgp_chol_bwd_phi_sym_f64(const double* P, double* S, int64_t n, int64_t ld, int64_t sP, int64_t batch, void* stream);
+/* precision changes of (batch, rows, cols) row-major blocks */
+int nsgp_cast_f64_to_f32(const double* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int64_t cols, void* stream);
+int nsgp_cast_f32_to_f64(const float* src, int64_t lds, double* dst, int64_t ldd, int64_t rows, int64_t cols, void* stream);
+/* counter-based standard normals (Philox4x32-10 + Box-Muller), keyed by
+ * (seed, stream_id, global_row, sample, column) so the union over data-parallel ranks equals the
+ * single-GPU draw: eps[s, i, c] for rows row0 .. row0+n-1. */
+int nsgp_philox_normal_f32(uint64_t seed, uint64_t stream_id, int64_t row0, int64_t S, int64_t n, int64_t b,
+                           float* eps, void* stream);
+int nsgp_philox_normal_f64(uint64_t seed, uint64_t stream_id, int64_t row0, int64_t S, int64_t n, int64_t b,
+                           double* eps, void* stream);
+/* fused Adam over one flat parameter buffer (torch.optim.Adam semantics, lr 0.01 in
+ * experiments/deepgp_spatial_bench.py:74-76); step is the 1-based step count; grad_scale
+ * multiplies the gradient first (1/world_size after a sum all-reduce). */
+int nsgp_adam_step_f32(float* p, const float* g, float* exp_avg, float* exp_avg_sq, int64_t n,
+                       float lr, float beta1, float beta2, float eps, int64_t step, float grad_scale,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NSGP_H */

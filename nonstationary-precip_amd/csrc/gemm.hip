@@ -1,0 +1,387 @@
+// gemm.hip -- dense contraction on the gfx950 matrix cores, exact f32 / f64 arithmetic.
+//
+//   C[b] = alpha * op(A[b]) * op(B[b]) + beta * C[b]
+//
+// f32: v_mfma_f32_32x32x2_f32 (64 FLOP/clk/SIMD, 155 TF chip peak; no xf32/TF32 on gfx950)
+// f64: v_mfma_f64_16x16x4_f64
+// This is the one genuine dense contraction of the path: L^-1 Kzx, Lq^T A, (S-I)A and their
+// adjoints in the whitened SVGP layer (gpytorch VariationalStrategy.forward), the
+// trailing updates of the blocked Cholesky, trtri, and K_xz Kzz^-1/2 of the SGPR path
+// (models/gibbs_kernels.py:225).
+//
+// Structure: 256-thread workgroup = 2x2 waves, LDS tiles stored k-major (As[k][m], Bs[k][n]) so an
+// MFMA operand fragment is one conflict-free ds_read per lane; global loads are 4 elements per lane
+// along whichever of (m|k) is contiguous, prefetched into registers one K-tile ahead, two LDS
+// buffers, one barrier per K-tile.  Triangular operands skip whole K-tiles and are masked in the
+// diagonal tiles; small outputs with a long inner dimension are split along K into slabs that a
+// second kernel sums in a fixed order (deterministic).
+#include "common.h"
+
+namespace {
+
+template <typename T> struct Mfma;
+template <> struct Mfma<float> {
+    static constexpr int MT = 32, KS = 2, NREG = 16, PAD = 4;
+    typedef float acc_t __attribute__((ext_vector_type(16)));
+    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int krow(int lane) { return lane >> 5; }      // k index of the operand lane
+    static __device__ __forceinline__ int mcol(int lane) { return lane & 31; }      // m / n index of the operand lane
+    static __device__ __forceinline__ int crow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+    static __device__ __forceinline__ int ccol(int lane) { return lane & 31; }
+};
+template <> struct Mfma<double> {
+    static constexpr int MT = 16, KS = 4, NREG = 4, PAD = 16;
+    typedef double acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int krow(int lane) { return lane >> 4; }
+    static __device__ __forceinline__ int mcol(int lane) { return lane & 15; }
+    static __device__ __forceinline__ int crow(int r, int lane) { return (lane >> 4) + 4 * r; }
+    static __device__ __forceinline__ int ccol(int lane) { return lane & 15; }
+};
+
+struct GemmArgs {
+    int64_t M, N, K;
+    int64_t sam, sak, sa1, sa2;
+    int64_t sbk, sbn, sb1, sb2;
+    int64_t ldc, sc1, sc2;
+    int64_t nb2;
+    int64_t ksplit, kper;         // K-slices (kper is a multiple of BK)
+    int64_t slab;                 // elements per (slice) slab = nb1*nb2*M*N when ksplit > 1
+    int flags;
+    int vecA, vecB;               // 16-byte vector global loads allowed for A / B
+    int modeA, modeB;             // 0: contiguous along k, 1: contiguous along m (n)
+};
+
+// 4-element register fragment loaded from global
+template <typename T> struct Frag4 { T v[4]; };
+
+template <typename T> __device__ __forceinline__ Frag4<T> ldg4(const T* p) {
+    Frag4<T> f;
+    if constexpr (sizeof(T) == 4) {
+        const float4 q = *reinterpret_cast<const float4*>(p);
+        f.v[0] = q.x; f.v[1] = q.y; f.v[2] = q.z; f.v[3] = q.w;
+    } else {
+        const double2 q0 = *reinterpret_cast<const double2*>(p);
+        const double2 q1 = *reinterpret_cast<const double2*>(p + 2);
+        f.v[0] = q0.x; f.v[1] = q0.y; f.v[2] = q1.x; f.v[3] = q1.y;
+    }
+    return f;
+}
+
+// Load 4 elements of an operand tile.  (r, k) is the element's (m|n, k) position; the 4 elements run
+// along k (mode 0) or along r (mode 1).  `lo`/`up`: zero where k > r (lower) / k < r (upper) for A,
+// and for B (r = n): "B lower" zero where n > k, "B upper" zero where n < k.
+template <typename T>
+__device__ __forceinline__ Frag4<T> load_operand4(const T* base, int64_t sr, int64_t sk, int64_t r, int64_t k,
+                                                  int64_t R, int64_t kend, int mode, int vec, bool zero_k_gt_r,
+                                                  bool zero_k_lt_r) {
+    Frag4<T> f;
+    if (mode == 0) {
+        if (vec && r < R && k + 3 < kend) {
+            f = ldg4(base + r * sr + k);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f.v[e] = (r < R && k + e < kend) ? base[r * sr + (k + e) * sk] : T(0);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (zero_k_gt_r && k + e > r) f.v[e] = T(0);
+            if (zero_k_lt_r && k + e < r) f.v[e] = T(0);
+        }
+    } else {
+        if (vec && k < kend && r + 3 < R) {
+            f = ldg4(base + k * sk + r);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f.v[e] = (k < kend && r + e < R) ? base[(r + e) * sr + k * sk] : T(0);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (zero_k_gt_r && k > r + e) f.v[e] = T(0);
+            if (zero_k_lt_r && k < r + e) f.v[e] = T(0);
+        }
+    }
+    return f;
+}
+
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, T alpha, const T* __restrict__ A,
+                                                   const T* __restrict__ B, T beta, T* __restrict__ C,
+                                                   T* __restrict__ slabs) {
+    using MF = Mfma<T>;
+    constexpr int BK = 16;
+    constexpr int MT = MF::MT, KS = MF::KS;
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int TM = WM / MT, TN = WN / MT;
+    constexpr int LDA = BM + MF::PAD, LDB = BN + MF::PAD;
+    constexpr int PA = BM * BK / 1024, PB = BN * BK / 1024;     // 4-element fragments per thread
+    __shared__ __attribute__((aligned(32))) T As[2][BK * LDA];
+    __shared__ __attribute__((aligned(32))) T Bs[2][BK * LDB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+    const int64_t bm = blockIdx.y, bn = blockIdx.x;
+    const int64_t z = blockIdx.z;
+    const int64_t slice = z % g.ksplit, bb = z / g.ksplit;
+    const int64_t b1 = bb / g.nb2, b2 = bb % g.nb2;
+    const int64_t m0 = bm * BM, n0 = bn * BN;
+
+    const T* Ab = A + b1 * g.sa1 + b2 * g.sa2;
+    const T* Bb = B + b1 * g.sb1 + b2 * g.sb2;
+    T* Cb = C + b1 * g.sc1 + b2 * g.sc2;
+
+    const bool aL = g.flags & NSGP_GEMM_A_LOWER, aU = g.flags & NSGP_GEMM_A_UPPER;
+    const bool bL = g.flags & NSGP_GEMM_B_LOWER, bU = g.flags & NSGP_GEMM_B_UPPER;
+    const bool cL = g.flags & NSGP_GEMM_C_LOWER;
+
+    // K range of this block: slice ∩ triangular support
+    int64_t kbeg = slice * g.kper, kend = kbeg + g.kper < g.K ? kbeg + g.kper : g.K;
+    if (aL) { const int64_t e = m0 + BM; if (e < kend) kend = e; }                 // k <= m
+    if (aU) { const int64_t s = m0 / BK * BK; if (s > kbeg) kbeg = s; }            // k >= m
+    if (bL) { const int64_t s = n0 / BK * BK; if (s > kbeg) kbeg = s; }            // k >= n
+    if (bU) { const int64_t e = n0 + BN; if (e < kend) kend = e; }                 // k <= n
+    const bool skip_block = cL && (n0 > m0 + BM - 1);
+    if (skip_block) kend = kbeg;
+    const int64_t nt = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+
+    typename MF::acc_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < MF::NREG; ++r) acc[i][j][r] = T(0);
+
+    Frag4<T> ra[PA], rb[PB];
+
+    auto gload = [&](int64_t k0) {
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            int64_t r, k;
+            if (g.modeA == 0) { r = m0 + p * 64 + (tid >> 2); k = k0 + (tid & 3) * 4; }
+            else { constexpr int TPR = BM / 4; r = m0 + (tid % TPR) * 4; k = k0 + p * (256 / TPR) + tid / TPR; }
+            ra[p] = load_operand4<T>(Ab, g.sam, g.sak, r, k, g.M, kend, g.modeA, g.vecA, aL, aU);
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            int64_t r, k;
+            if (g.modeB == 0) { r = n0 + p * 64 + (tid >> 2); k = k0 + (tid & 3) * 4; }
+            else { constexpr int TPR = BN / 4; r = n0 + (tid % TPR) * 4; k = k0 + p * (256 / TPR) + tid / TPR; }
+            // B(k,n): "lower" zero where n > k  <=> k < r ; "upper" zero where n < k <=> k > r
+            rb[p] = load_operand4<T>(Bb, g.sbn, g.sbk, r, k, g.N, kend, g.modeB, g.vecB, bU, bL);
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            if (g.modeA == 0) {
+                const int r = p * 64 + (tid >> 2), k = (tid & 3) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) As[buf][(k + e) * LDA + r] = ra[p].v[e];
+            } else {
+                constexpr int TPR = BM / 4;
+                const int r = (tid % TPR) * 4, k = p * (256 / TPR) + tid / TPR;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) As[buf][k * LDA + r + e] = ra[p].v[e];
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            if (g.modeB == 0) {
+                const int r = p * 64 + (tid >> 2), k = (tid & 3) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Bs[buf][(k + e) * LDB + r] = rb[p].v[e];
+            } else {
+                constexpr int TPR = BN / 4;
+                const int r = (tid % TPR) * 4, k = p * (256 / TPR) + tid / TPR;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Bs[buf][k * LDB + r + e] = rb[p].v[e];
+            }
+        }
+    };
+
+    if (nt > 0) {
+        gload(kbeg);
+        sstore(0);
+        __syncthreads();
+        const int kr = MF::krow(lane), mc = MF::mcol(lane);
+        for (int64_t t = 0; t < nt; ++t) {
+            const int buf = (int)(t & 1);
+            if (t + 1 < nt) gload(kbeg + (t + 1) * BK);
+            const T* as = &As[buf][0];
+            const T* bs = &Bs[buf][0];
+#pragma unroll
+            for (int kk = 0; kk < BK / KS; ++kk) {
+                T af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = as[(kk * KS + kr) * LDA + wm0 + i * MT + mc];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = bs[(kk * KS + kr) * LDB + wn0 + j * MT + mc];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(af[i], bf[j], acc[i][j]);
+            }
+            if (t + 1 < nt) sstore(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // epilogue
+    const bool to_slab = g.ksplit > 1;
+    T* out = to_slab ? slabs + slice * g.slab + bb * g.M * g.N : Cb;
+    const int64_t ldo = to_slab ? g.N : g.ldc;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < MF::NREG; ++r) {
+                const int64_t row = m0 + wm0 + i * MT + MF::crow(r, lane);
+                const int64_t col = n0 + wn0 + j * MT + MF::ccol(lane);
+                if (row < g.M && col < g.N) {
+                    T v = acc[i][j][r];
+                    if (to_slab) {
+                        out[row * ldo + col] = v;
+                    } else {
+                        if (cL && col > row) {
+                            if (beta == T(0)) out[row * ldo + col] = T(0);
+                        } else {
+                            v *= alpha;
+                            if (beta != T(0)) v += beta * out[row * ldo + col];
+                            out[row * ldo + col] = v;
+                        }
+                    }
+                }
+            }
+}
+
+// C = alpha * sum_s slab[s] + beta * C   (fixed summation order)
+template <typename T>
+__global__ void splitk_reduce_kernel(GemmArgs g, T alpha, const T* __restrict__ slabs, T beta, T* __restrict__ C,
+                                     int64_t nb) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per = g.M * g.N;
+    if (idx >= nb * per) return;
+    const int64_t bb = idx / per, e = idx % per;
+    const int64_t row = e / g.N, col = e % g.N;
+    const int64_t b1 = bb / g.nb2, b2 = bb % g.nb2;
+    T* c = C + b1 * g.sc1 + b2 * g.sc2 + row * g.ldc + col;
+    if ((g.flags & NSGP_GEMM_C_LOWER) && col > row) {
+        if (beta == T(0)) *c = T(0);
+        return;
+    }
+    T s = T(0);
+    for (int64_t k = 0; k < g.ksplit; ++k) s += slabs[k * g.slab + idx];
+    s *= alpha;
+    if (beta != T(0)) s += beta * *c;
+    *c = s;
+}
+
+struct Plan { int big; int64_t ksplit, kper; };
+
+template <typename T> Plan make_plan(int64_t M, int64_t N, int64_t K, int64_t nb, int flags) {
+    Plan p;
+    const bool can_split = !(flags & NSGP_GEMM_NO_SPLITK) && K >= 512;
+    int64_t maxks = can_split ? K / 256 : 1;
+    if (maxks > 64) maxks = 64;
+    if (maxks < 1) maxks = 1;
+    const int64_t tiles_big = cdiv64(M, 128) * cdiv64(N, 128) * nb;
+    // 128x128 tiles (f32 only) when, with K-splitting, they still fill the 256 CUs
+    p.big = sizeof(T) == 4 && tiles_big * maxks >= 256;
+    const int64_t bm = p.big ? 128 : 64;
+    const int64_t tiles = cdiv64(M, bm) * cdiv64(N, bm) * nb;
+    int64_t ks = 1;
+    if (tiles < 512) {
+        ks = cdiv64(512, tiles);
+        if (ks > maxks) ks = maxks;
+    }
+    p.kper = cdiv64(cdiv64(K, ks), 16) * 16;
+    if (p.kper < 16) p.kper = 16;
+    p.ksplit = cdiv64(K, p.kper);
+    if (p.ksplit < 1) p.ksplit = 1;
+    return p;
+}
+
+template <typename T>
+int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam, int64_t sak, int64_t sa1,
+              int64_t sa2, const T* B, int64_t sbk, int64_t sbn, int64_t sb1, int64_t sb2, T beta, T* C,
+              int64_t ldc, int64_t sc1, int64_t sc2, int64_t nb1, int64_t nb2, int flags, void* ws, size_t wsb,
+              void* stream) {
+    if (M < 0) return -1; if (N < 0) return -2; if (K < 0) return -3;
+    if (nb1 < 1 || nb2 < 1) return -20;
+    if (M == 0 || N == 0) return 0;
+    if (!A && K > 0) return -5; if (!B && K > 0) return -10; if (!C) return -16; if (ldc < N) return -17;
+    if ((flags & NSGP_GEMM_A_LOWER) && (flags & NSGP_GEMM_A_UPPER)) return -22;
+    if ((flags & NSGP_GEMM_B_LOWER) && (flags & NSGP_GEMM_B_UPPER)) return -22;
+    const int64_t nb = nb1 * nb2;
+    Plan p = make_plan<T>(M, N, K, nb, flags);
+    GemmArgs g;
+    g.M = M; g.N = N; g.K = K;
+    g.sam = sam; g.sak = sak; g.sa1 = sa1; g.sa2 = sa2;
+    g.sbk = sbk; g.sbn = sbn; g.sb1 = sb1; g.sb2 = sb2;
+    g.ldc = ldc; g.sc1 = sc1; g.sc2 = sc2; g.nb2 = nb2;
+    g.ksplit = p.ksplit; g.kper = p.kper; g.slab = nb * M * N; g.flags = flags;
+    g.modeA = (sak == 1) ? 0 : (sam == 1 ? 1 : 0);
+    g.modeB = (sbk == 1) ? 0 : (sbn == 1 ? 1 : 0);
+    const size_t al = 4 * sizeof(T);
+    auto vec_ok = [&](const void* ptr, int64_t unit, int64_t other, int64_t s1, int64_t s2) {
+        return unit == 1 && other % 4 == 0 && s1 % 4 == 0 && s2 % 4 == 0 && ((uintptr_t)ptr % al) == 0;
+    };
+    g.vecA = g.modeA == 0 ? vec_ok(A, sak, sam, sa1, sa2) : vec_ok(A, sam, sak, sa1, sa2);
+    g.vecB = g.modeB == 0 ? vec_ok(B, sbk, sbn, sb1, sb2) : vec_ok(B, sbn, sbk, sb1, sb2);
+    T* slabs = nullptr;
+    if (p.ksplit > 1) {
+        const size_t need = (size_t)p.ksplit * g.slab * sizeof(T);
+        if (!ws || wsb < need) return -23;
+        slabs = (T*)ws;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t bmn = p.big ? 128 : 64;
+    dim3 grid((unsigned)cdiv64(N, bmn), (unsigned)cdiv64(M, bmn), (unsigned)(nb * g.ksplit));
+    if (grid.y > 65535 || grid.z > 65535) return -24;
+    if (p.big) {
+        if constexpr (sizeof(T) == 4)
+            hipLaunchKernelGGL((gemm_kernel<T, 128, 128>), grid, dim3(256), 0, st, g, alpha, A, B, beta, C, slabs);
+    } else {
+        hipLaunchKernelGGL((gemm_kernel<T, 64, 64>), grid, dim3(256), 0, st, g, alpha, A, B, beta, C, slabs);
+    }
+    if (g.ksplit > 1) {
+        const int64_t tot = nb * M * N;
+        hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, st, g, alpha,
+                           (const T*)slabs, beta, C, nb);
+    }
+    return nsgp_launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t nsgp_gemm_workspace(int64_t M, int64_t N, int64_t K, int64_t nb1, int64_t nb2, int elem_size) {
+    if (M <= 0 || N <= 0 || K <= 0 || nb1 < 1 || nb2 < 1) return 0;
+    const int64_t nb = nb1 * nb2;
+    const Plan p = elem_size == 4 ? make_plan<float>(M, N, K, nb, 0) : make_plan<double>(M, N, K, nb, 0);
+    return p.ksplit > 1 ? (size_t)p.ksplit * nb * M * N * elem_size : 0;
+}
+
+int nsgp_gemm_f32(int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t sam, int64_t sak,
+                  int64_t sa1, int64_t sa2, const float* B, int64_t sbk, int64_t sbn, int64_t sb1, int64_t sb2,
+                  float beta, float* C, int64_t ldc, int64_t sc1, int64_t sc2, int64_t nb1, int64_t nb2, int flags,
+                  void* ws, size_t wsb, void* stream) {
+    return gemm_impl<float>(M, N, K, alpha, A, sam, sak, sa1, sa2, B, sbk, sbn, sb1, sb2, beta, C, ldc, sc1, sc2,
+                            nb1, nb2, flags, ws, wsb, stream);
+}
+int nsgp_gemm_f64(int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t sam, int64_t sak,
+                  int64_t sa1, int64_t sa2, const double* B, int64_t sbk, int64_t sbn, int64_t sb1, int64_t sb2,
+                  double beta, double* C, int64_t ldc, int64_t sc1, int64_t sc2, int64_t nb1, int64_t nb2,
+                  int flags, void* ws, size_t wsb, void* stream) {
+    return gemm_impl<double>(M, N, K, alpha, A, sam, sak, sa1, sa2, B, sbk, sbn, sb1, sb2, beta, C, ldc, sc1, sc2,
+                             nb1, nb2, flags, ws, wsb, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,169 @@
+// misc.hip -- small stream-ordered helpers: Cholesky-backward symmetrisation, precision casts,
+// counter-based normals (Philox4x32-10), fused Adam, library identification.
+#include <cmath>
+#include "common.h"
+
+namespace {
+
+template <typename T>
+__global__ void phi_sym_kernel(const T* __restrict__ P, T* __restrict__ S, int64_t n, int64_t ld, int64_t sP,
+                               int64_t batch) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= batch * n * n) return;
+    const int64_t b = idx / (n * n), e = idx % (n * n);
+    const int64_t i = e / n, j = e % n;
+    const T* Pb = P + b * sP;
+    // Phi keeps the lower triangle and halves the diagonal; S = Phi + Phi^T
+    S[b * sP + i * ld + j] = (i >= j) ? Pb[i * ld + j] : Pb[j * ld + i];
+}
+
+template <typename TS, typename TD>
+__global__ void cast_kernel(const TS* __restrict__ src, int64_t lds, TD* __restrict__ dst, int64_t ldd, int64_t rows,
+                            int64_t cols) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * cols) return;
+    const int64_t r = idx / cols, c = idx % cols;
+    dst[r * ldd + c] = (TD)src[r * lds + c];
+}
+
+// ---- Philox4x32-10 (Salmon et al. 2011) ------------------------------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+    const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+}
+
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+// eps[s, i, c] for global row row0 + i: counter = (row_lo, row_hi, s | (c/4) << 20, stream_id_lo),
+// key = (seed_lo, seed_hi ^ stream_id_hi); words (2q, 2q+1) -> Box-Muller pair q; column c uses
+// normal number (c % 4): pair (c%4)/2, cos for even, sin for odd.
+template <typename T>
+__global__ void philox_normal_kernel(uint64_t seed, uint64_t stream_id, int64_t row0, int64_t S, int64_t n, int64_t b,
+                                     T* __restrict__ eps) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t bq = (b + 3) / 4;
+    if (idx >= S * n * bq) return;
+    const int64_t cq = idx % bq, i = (idx / bq) % n, s = idx / (bq * n);
+    const uint64_t row = (uint64_t)(row0 + i);
+    uint32_t c[4] = {(uint32_t)row, (uint32_t)(row >> 32), (uint32_t)s | ((uint32_t)cq << 20), (uint32_t)stream_id};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(stream_id >> 32));
+    const double two_m32 = 2.3283064365386963e-10;       // 2^-32
+    double z[4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const double u1 = ((double)c[2 * q] + 0.5) * two_m32;
+        const double u2 = ((double)c[2 * q + 1] + 0.5) * two_m32;
+        const double r = sqrt(-2.0 * log(u1));
+        const double th = 6.283185307179586476925286766559 * u2;
+        z[2 * q] = r * cos(th);
+        z[2 * q + 1] = r * sin(th);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t col = cq * 4 + k;
+        if (col < b) eps[(s * n + i) * b + col] = (T)z[k];
+    }
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float bc1,
+                            float bc2_sqrt, float gscale) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const float gr = g[idx] * gscale;
+    const float mi = b1 * m[idx] + (1.0f - b1) * gr;
+    const float vi = b2 * v[idx] + (1.0f - b2) * gr * gr;
+    m[idx] = mi;
+    v[idx] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[idx] -= (lr / bc1) * mi / denom;
+}
+
+template <typename T>
+int phi_impl(const T* P, T* S, int64_t n, int64_t ld, int64_t sP, int64_t batch, void* stream) {
+    if (!P) return -1; if (!S) return -2; if (n < 0) return -3; if (ld < n) return -4; if (batch < 0) return -6;
+    const int64_t tot = batch * n * n;
+    if (tot == 0) return 0;
+    hipLaunchKernelGGL((phi_sym_kernel<T>), dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, (hipStream_t)stream, P, S,
+                       n, ld, sP, batch);
+    return nsgp_launch_status();
+}
+
+template <typename TS, typename TD>
+int cast_impl(const TS* src, int64_t lds, TD* dst, int64_t ldd, int64_t rows, int64_t cols, void* stream) {
+    if (!src) return -1; if (lds < cols) return -2; if (!dst) return -3; if (ldd < cols) return -4;
+    if (rows < 0) return -5; if (cols < 0) return -6;
+    const int64_t tot = rows * cols;
+    if (tot == 0) return 0;
+    hipLaunchKernelGGL((cast_kernel<TS, TD>), dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       lds, dst, ldd, rows, cols);
+    return nsgp_launch_status();
+}
+
+template <typename T>
+int philox_impl(uint64_t seed, uint64_t stream_id, int64_t row0, int64_t S, int64_t n, int64_t b, T* eps,
+                void* stream) {
+    if (row0 < 0) return -3; if (S < 0 || S >= (1 << 20)) return -4; if (n < 0) return -5;
+    if (b < 0 || b > 4 * 4096) return -6; if (!eps) return -7;
+    const int64_t tot = S * n * ((b + 3) / 4);
+    if (tot == 0) return 0;
+    hipLaunchKernelGGL((philox_normal_kernel<T>), dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, (hipStream_t)stream,
+                       seed, stream_id, row0, S, n, b, eps);
+    return nsgp_launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int nsgp_abi_version(void) { return 1; }
+const char* nsgp_build_arch(void) { return "gfx950"; }
+
+int nsgp_chol_bwd_phi_sym_f32(const float* P, float* S, int64_t n, int64_t ld, int64_t sP, int64_t batch,
+                              void* stream) {
+    return phi_impl<float>(P, S, n, ld, sP, batch, stream);
+}
+int nsgp_chol_bwd_phi_sym_f64(const double* P, double* S, int64_t n, int64_t ld, int64_t sP, int64_t batch,
+                              void* stream) {
+    return phi_impl<double>(P, S, n, ld, sP, batch, stream);
+}
+int nsgp_cast_f64_to_f32(const double* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int64_t cols,
+                         void* stream) {
+    return cast_impl<double, float>(src, lds, dst, ldd, rows, cols, stream);
+}
+int nsgp_cast_f32_to_f64(const float* src, int64_t lds, double* dst, int64_t ldd, int64_t rows, int64_t cols,
+                         void* stream) {
+    return cast_impl<float, double>(src, lds, dst, ldd, rows, cols, stream);
+}
+int nsgp_philox_normal_f32(uint64_t seed, uint64_t stream_id, int64_t row0, int64_t S, int64_t n, int64_t b,
+                           float* eps, void* stream) {
+    return philox_impl<float>(seed, stream_id, row0, S, n, b, eps, stream);
+}
+int nsgp_philox_normal_f64(uint64_t seed, uint64_t stream_id, int64_t row0, int64_t S, int64_t n, int64_t b,
+                           double* eps, void* stream) {
+    return philox_impl<double>(seed, stream_id, row0, S, n, b, eps, stream);
+}
+int nsgp_adam_step_f32(float* p, const float* g, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                       float beta2, float eps, int64_t step, float grad_scale, void* stream) {
+    if (!p) return -1; if (!g) return -2; if (!exp_avg) return -3; if (!exp_avg_sq) return -4; if (n < 0) return -5;
+    if (step < 1) return -10;
+    if (n == 0) return 0;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, exp_avg,
+                       exp_avg_sq, n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale);
+    return nsgp_launch_status();
+}
+
+}  // extern "C"

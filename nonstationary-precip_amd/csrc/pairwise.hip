@@ -1,0 +1,633 @@
+// pairwise.hip -- kernel-matrix builds K[i,j] = k(row_i, col_j) and their backward reductions.
+//
+//   K1 Gibbs (models/gibbs_kernels.py:154-162), K2 batched RBF-ARD (gpytorch ScaleKernel(RBF),
+//   models/dgps.py:44-46), K3 Paciorek-Schervish D=2 (models/multivariate_gibbs_kernel.py:98-150).
+//
+// Forward: HBM-write bound.  One 256-thread workgroup owns a 32 x (64*CPT) tile; a lane owns CPT
+// consecutive columns (16 B) so every wave store is one contiguous 1 KiB line group; the column
+// operands live in registers for the whole tile and the row operands are wave-uniform loads.
+// Algorithmic bytes per build: s*(n1*n2 + 2*D*(n1+n2)).
+//
+// Backward: one pass over G (dLoss/dK).  A workgroup owns a 64 x 256 tile: wave w walks rows
+// w, w+4, ..; a lane covers 4 columns 64 apart (coalesced G reads).  Row-side gradients are
+// wave-reduced once per row (amortised over 256 columns), column-side gradients stay in
+// registers and are combined across the 4 waves through LDS.  Tile partials go to a workspace and
+// a second tiny kernel sums them: deterministic, no atomics.
+#include "common.h"
+
+namespace {
+
+template <typename T> struct Cpt;
+template <> struct Cpt<float> { static constexpr int v = 4; };
+template <> struct Cpt<double> { static constexpr int v = 2; };
+
+template <int D> struct DimMax { static constexpr int v = D ? D : NSGP_MAX_DIM; };
+
+// ------------------------------------------------------------------------------------------
+// functors
+// ------------------------------------------------------------------------------------------
+template <typename T, int D> struct GibbsOp {
+    static constexpr int DM = DimMax<D>::v;
+    static constexpr int NR = 2 * DM, NC = 2 * DM, NG = 1;
+    const T *x1, *x2, *l1, *l2;
+    int64_t n1, n2;
+    int Drt;
+    const T* osp;                          // device scalar or nullptr (= 1)
+    __device__ __forceinline__ T os() const { return osp ? osp[0] : T(1); }
+    struct P { T x[DM]; T l[DM]; };
+    __device__ __forceinline__ P row(int64_t, int64_t i) const {
+        P p;
+#pragma unroll
+        for (int d = 0; d < DM; ++d) {
+            const bool on = D || d < Drt;
+            p.x[d] = on ? x1[i * Drt + d] : T(0);
+            p.l[d] = on ? l1[(int64_t)d * n1 + i] : T(1);
+        }
+        return p;
+    }
+    __device__ __forceinline__ P col(int64_t, int64_t j) const {
+        P p;
+#pragma unroll
+        for (int d = 0; d < DM; ++d) {
+            const bool on = D || d < Drt;
+            p.x[d] = on ? x2[j * Drt + d] : T(0);
+            p.l[d] = on ? l2[(int64_t)d * n2 + j] : T(1);
+        }
+        return p;
+    }
+    // unscaled kernel value (pre * exp)
+    __device__ __forceinline__ T base(const P& r, const P& c) const {
+        T pre = T(1), ex = T(0);
+#pragma unroll
+        for (int d = 0; d < DM; ++d) {
+            if (D || d < Drt) {
+                const T s = r.l[d] * r.l[d] + c.l[d] * c.l[d];
+                const T inv = T(1) / s;
+                const T df = r.x[d] - c.x[d];
+                pre *= T(2) * r.l[d] * c.l[d] * inv;
+                ex += df * df * inv;
+            }
+        }
+        return t_sqrt(pre) * t_exp(-ex);
+    }
+    __device__ __forceinline__ T eval(int64_t, const P& r, const P& c) const { return os() * base(r, c); }
+    // accumulate g * d k / d(param) into row / col / global accumulators
+    __device__ __forceinline__ void grad(int64_t, const P& r, const P& c, T g, T* ra, T* ca, T* ga) const {
+        const T kb = base(r, c);
+        ga[0] += g * kb;
+        const T w = g * kb * os();
+#pragma unroll
+        for (int d = 0; d < DM; ++d) {
+            if (D || d < Drt) {
+                const T a = r.l[d], b = c.l[d];
+                const T s = a * a + b * b;
+                const T inv = T(1) / s;
+                const T df = r.x[d] - c.x[d];
+                const T q = df * df * inv * inv;          // delta^2 / s^2
+                ra[d] += w * (T(0.5) / a - a * inv + T(2) * a * q);
+                ca[d] += w * (T(0.5) / b - b * inv + T(2) * b * q);
+                const T gx = T(2) * w * df * inv;
+                ra[DM + d] -= gx;
+                ca[DM + d] += gx;
+            }
+        }
+    }
+};
+
+template <typename T, int D> struct RbfOp {
+    static constexpr int DM = DimMax<D>::v;
+    static constexpr int NR = DM, NC = DM, NG = DM + 1;
+    const T *x1, *x2, *ls, *os;           // ls:(batch,D) os:(batch)
+    int64_t n1, n2, sx1, sx2;
+    int Drt;
+    struct P { T x[DM]; };                // pre-divided by the lengthscale
+    __device__ __forceinline__ P row(int64_t b, int64_t i) const {
+        P p;
+#pragma unroll
+        for (int d = 0; d < DM; ++d)
+            p.x[d] = (D || d < Drt) ? x1[b * sx1 + i * Drt + d] / ls[b * Drt + d] : T(0);
+        return p;
+    }
+    __device__ __forceinline__ P col(int64_t b, int64_t j) const {
+        P p;
+#pragma unroll
+        for (int d = 0; d < DM; ++d)
+            p.x[d] = (D || d < Drt) ? x2[b * sx2 + j * Drt + d] / ls[b * Drt + d] : T(0);
+        return p;
+    }
+    __device__ __forceinline__ T base(const P& r, const P& c) const {
+        T ex = T(0);
+#pragma unroll
+        for (int d = 0; d < DM; ++d) {
+            const T df = r.x[d] - c.x[d];
+            ex += df * df;
+        }
+        return t_exp(T(-0.5) * ex);
+    }
+    __device__ __forceinline__ T eval(int64_t b, const P& r, const P& c) const { return os[b] * base(r, c); }
+    // row/col accumulators are in units of d/d(x/ls) ("scaled x"); pass 2 divides by ls.
+    __device__ __forceinline__ void grad(int64_t b, const P& r, const P& c, T g, T* ra, T* ca, T* ga) const {
+        const T kb = base(r, c);
+        ga[DM] += g * kb;
+        const T w = g * kb * os[b];
+#pragma unroll
+        for (int d = 0; d < DM; ++d) {
+            const T df = r.x[d] - c.x[d];
+            ra[d] -= w * df;
+            ca[d] += w * df;
+            ga[d] += w * df * df;             // * 1/ls applied in pass 2
+        }
+    }
+};
+
+template <typename T> struct PsOp {
+    static constexpr int NR = 4, NC = 4, NG = 1;      // NG unused (kept 1 for array sizing)
+    const T *x1, *x2, *s1, *s2;
+    T jit;
+    struct P { T x[2]; T s[4]; T q;  /* det^(1/4) */ };
+    __device__ __forceinline__ P load(const T* x, const T* s, int64_t i) const {
+        P p;
+        p.x[0] = x[2 * i]; p.x[1] = x[2 * i + 1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) p.s[k] = s[4 * i + k];
+        const T det = p.s[0] * p.s[3] - p.s[1] * p.s[2];
+        p.q = t_sqrt(t_sqrt(det));
+        return p;
+    }
+    __device__ __forceinline__ P row(int64_t, int64_t i) const { return load(x1, s1, i); }
+    __device__ __forceinline__ P col(int64_t, int64_t j) const { return load(x2, s2, j); }
+    __device__ __forceinline__ T eval(int64_t, const P& r, const P& c) const {
+        const T a0 = T(0.5) * (r.s[0] + c.s[0]), a1 = T(0.5) * (r.s[1] + c.s[1]);
+        const T a2 = T(0.5) * (r.s[2] + c.s[2]), a3 = T(0.5) * (r.s[3] + c.s[3]);
+        const T detA = a0 * a3 - a1 * a2;
+        const T b0 = a0 + jit, b3 = a3 + jit;
+        const T detB = b0 * b3 - a1 * a2;
+        const T d0 = r.x[0] - c.x[0], d1 = r.x[1] - c.x[1];
+        const T quad = (b3 * d0 * d0 - (a1 + a2) * d0 * d1 + b0 * d1 * d1) / detB;
+        return r.q * c.q / t_sqrt(detA) * t_exp(-quad);
+    }
+    __device__ __forceinline__ void grad(int64_t, const P& r, const P& c, T g, T* ra, T* ca, T*) const {
+        const T a0 = T(0.5) * (r.s[0] + c.s[0]), a1 = T(0.5) * (r.s[1] + c.s[1]);
+        const T a2 = T(0.5) * (r.s[2] + c.s[2]), a3 = T(0.5) * (r.s[3] + c.s[3]);
+        const T detA = a0 * a3 - a1 * a2;
+        const T b0 = a0 + jit, b3 = a3 + jit;
+        const T detB = b0 * b3 - a1 * a2;
+        const T d0 = r.x[0] - c.x[0], d1 = r.x[1] - c.x[1];
+        const T quad = (b3 * d0 * d0 - (a1 + a2) * d0 * d1 + b0 * d1 * d1) / detB;
+        const T k = r.q * c.q / t_sqrt(detA) * t_exp(-quad);
+        const T w = g * k;
+        // B^-1 d  and  B^-T d
+        const T iB = T(1) / detB;
+        const T v0 = (b3 * d0 - a1 * d1) * iB, v1 = (-a2 * d0 + b0 * d1) * iB;     // B^-1 d
+        const T u0 = (b3 * d0 - a2 * d1) * iB, u1 = (-a1 * d0 + b0 * d1) * iB;     // B^-T d
+        // shared term: -1/4 A^-T + 1/2 u v^T
+        const T iA = T(0.25) / detA;
+        const T sh0 = -iA * a3 + T(0.5) * u0 * v0;
+        const T sh1 = iA * a2 + T(0.5) * u0 * v1;
+        const T sh2 = iA * a1 + T(0.5) * u1 * v0;
+        const T sh3 = -iA * a0 + T(0.5) * u1 * v1;
+        const T dr = T(0.25) / (r.s[0] * r.s[3] - r.s[1] * r.s[2]);
+        const T dc = T(0.25) / (c.s[0] * c.s[3] - c.s[1] * c.s[2]);
+        ra[0] += w * (sh0 + dr * r.s[3]); ra[1] += w * (sh1 - dr * r.s[2]);
+        ra[2] += w * (sh2 - dr * r.s[1]); ra[3] += w * (sh3 + dr * r.s[0]);
+        ca[0] += w * (sh0 + dc * c.s[3]); ca[1] += w * (sh1 - dc * c.s[2]);
+        ca[2] += w * (sh2 - dc * c.s[1]); ca[3] += w * (sh3 + dc * c.s[0]);
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// forward tile kernel
+// ------------------------------------------------------------------------------------------
+constexpr int FWD_TI = 32;
+
+template <typename T, typename Op>
+__global__ __launch_bounds__(256) void pairwise_fwd_kernel(Op op, int64_t n1, int64_t n2, T diag_add_v,
+                                                           const T* __restrict__ diag_add_p,
+                                                           T* __restrict__ K, int64_t ldk, int64_t sK, int vec_ok) {
+    constexpr int CPT = Cpt<T>::v;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t b = blockIdx.z;
+    const int64_t j0 = ((int64_t)blockIdx.x * 64 + lane) * CPT;
+    const int64_t i0 = (int64_t)blockIdx.y * FWD_TI;
+    if (j0 >= n2) return;
+    const T diag_add = diag_add_p ? diag_add_p[0] : diag_add_v;
+    typename Op::P cols[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) cols[c] = op.col(b, j0 + c < n2 ? j0 + c : n2 - 1);
+    T* Kb = K + b * sK;
+    const bool full = vec_ok && (j0 + CPT <= n2);
+    for (int r = w; r < FWD_TI; r += 4) {
+        const int64_t i = i0 + r;
+        if (i >= n1) break;
+        const typename Op::P rp = op.row(b, i);
+        T v[CPT];
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            v[c] = op.eval(b, rp, cols[c]);
+            if (i == j0 + c) v[c] += diag_add;
+        }
+        T* dst = Kb + i * ldk + j0;
+        if (full) {
+            if constexpr (CPT == 4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            else *reinterpret_cast<double2*>(dst) = make_double2(v[0], v[1]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) if (j0 + c < n2) dst[c] = v[c];
+        }
+    }
+}
+
+template <typename T, typename Op>
+int launch_fwd(const Op& op, int64_t batch, int64_t n1, int64_t n2, T diag_add, const T* diag_add_p, T* K,
+               int64_t ldk, int64_t sK, void* stream) {
+    if (n1 == 0 || n2 == 0 || batch == 0) return 0;
+    constexpr int CPT = Cpt<T>::v;
+    const int vec_ok = (ldk % CPT == 0) && (sK % CPT == 0) && ((uintptr_t)K % (CPT * sizeof(T)) == 0);
+    dim3 grid((unsigned)cdiv64(n2, 64 * CPT), (unsigned)cdiv64(n1, FWD_TI), (unsigned)batch);
+    hipLaunchKernelGGL((pairwise_fwd_kernel<T, Op>), grid, dim3(256), 0, (hipStream_t)stream, op, n1, n2,
+                       diag_add, diag_add_p, K, ldk, sK, vec_ok);
+    return nsgp_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------
+// backward tile kernel (pass 1) and partial reduction (pass 2)
+// ------------------------------------------------------------------------------------------
+constexpr int BWD_TI = 64, BWD_TJ = 256;
+
+template <typename T, typename Op>
+__global__ __launch_bounds__(256) void pairwise_bwd_kernel(Op op, int64_t n1, int64_t n2,
+                                                           const T* __restrict__ G, int64_t ldg, int64_t sG,
+                                                           T* __restrict__ P1, T* __restrict__ P2,
+                                                           T* __restrict__ PG) {
+    constexpr int NR = Op::NR, NC = Op::NC, NG = Op::NG;
+    __shared__ T lds[256 * NC];
+    __shared__ T lds_g[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t b = blockIdx.z;
+    const int64_t tj = blockIdx.x, ti = blockIdx.y;
+    const int64_t ntj = gridDim.x, nti = gridDim.y;
+    const int64_t j0 = tj * BWD_TJ, i0 = ti * BWD_TI;
+    const T* Gb = G + b * sG;
+
+    typename Op::P cols[4];
+    bool cok[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int64_t j = j0 + c * 64 + lane;
+        cok[c] = j < n2;
+        cols[c] = op.col(b, cok[c] ? j : n2 - 1);
+    }
+    T ca[4][NC];
+    T ga[NG];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int k = 0; k < NC; ++k) ca[c][k] = T(0);
+#pragma unroll
+    for (int k = 0; k < NG; ++k) ga[k] = T(0);
+
+    for (int r = w; r < BWD_TI; r += 4) {
+        const int64_t i = i0 + r;
+        if (i >= n1) break;                         // wave-uniform
+        const typename Op::P rp = op.row(b, i);
+        T ra[NR];
+#pragma unroll
+        for (int k = 0; k < NR; ++k) ra[k] = T(0);
+        T gv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) gv[c] = cok[c] ? Gb[i * ldg + j0 + c * 64 + lane] : T(0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) op.grad(b, rp, cols[c], gv[c], ra, ca[c], ga);
+#pragma unroll
+        for (int k = 0; k < NR; ++k) ra[k] = wave_sum(ra[k]);
+        if (lane == 0) {
+            T* dst = P1 + ((b * ntj + tj) * n1 + i) * NR;
+#pragma unroll
+            for (int k = 0; k < NR; ++k) dst[k] = ra[k];
+        }
+    }
+    // column side: combine the 4 waves through LDS, one chunk of 64 columns at a time
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        for (int ww = 0; ww < 4; ++ww) {
+            if (w == ww) {
+#pragma unroll
+                for (int k = 0; k < NC; ++k) {
+                    T* p = &lds[(c * 64 + lane) * NC + k];
+                    *p = (ww == 0) ? ca[c][k] : (*p + ca[c][k]);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    {
+        const int64_t j = j0 + threadIdx.x;
+        if (j < n2) {
+            T* dst = P2 + ((b * nti + ti) * n2 + j) * NC;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) dst[k] = lds[threadIdx.x * NC + k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+        const T s = block_sum_256(ga[k], lds_g);
+        if (threadIdx.x == 0) PG[((b * nti + ti) * ntj + tj) * NG + k] = s;
+    }
+}
+
+// out descriptor for pass 2: value k of item i goes to ptr[k][b*bstride[k] + i*stride[k]] * scale
+template <typename T> struct OutDesc {
+    T* ptr[2 * NSGP_MAX_DIM];
+    int64_t stride[2 * NSGP_MAX_DIM];
+    int64_t bstride[2 * NSGP_MAX_DIM];
+    const T* div[2 * NSGP_MAX_DIM];       // optional per-batch divisor array (RBF: lengthscale), index b*divstride+divoff
+    int64_t divstride[2 * NSGP_MAX_DIM];
+    int64_t divoff[2 * NSGP_MAX_DIM];
+    int nval;
+};
+
+template <typename T>
+__global__ void reduce_items_kernel(const T* __restrict__ P, int64_t ntiles, int64_t n, OutDesc<T> od) {
+    const int64_t b = blockIdx.z;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * od.nval) return;
+    const int64_t i = idx / od.nval;
+    const int k = (int)(idx % od.nval);
+    if (!od.ptr[k]) return;
+    T s = T(0);
+    const T* p = P + b * ntiles * n * od.nval + idx;
+    for (int64_t t = 0; t < ntiles; ++t) s += p[t * n * od.nval];
+    if (od.div[k]) s /= od.div[k][b * od.divstride[k] + od.divoff[k]];
+    od.ptr[k][b * od.bstride[k] + i * od.stride[k]] = s;
+}
+
+// global values: one block per (batch), sums `nparts` partials of `nval` values each
+template <typename T>
+__global__ __launch_bounds__(256) void reduce_globals_kernel(const T* __restrict__ PG, int64_t nparts, OutDesc<T> od) {
+    __shared__ T lds[4];
+    const int64_t b = blockIdx.x;
+    for (int k = 0; k < od.nval; ++k) {
+        T s = T(0);
+        for (int64_t t = threadIdx.x; t < nparts; t += 256) s += PG[(b * nparts + t) * od.nval + k];
+        s = block_sum_256(s, lds);
+        if (threadIdx.x == 0 && od.ptr[k]) {
+            if (od.div[k]) s /= od.div[k][b * od.divstride[k] + od.divoff[k]];
+            od.ptr[k][b * od.bstride[k]] = s;
+        }
+        __syncthreads();
+    }
+}
+
+template <typename Op> size_t bwd_ws_elems(int64_t batch, int64_t n1, int64_t n2) {
+    const int64_t ntj = cdiv64(n2, BWD_TJ), nti = cdiv64(n1, BWD_TI);
+    return (size_t)(batch * (ntj * n1 * Op::NR + nti * n2 * Op::NC + nti * ntj * Op::NG));
+}
+
+template <typename T, typename Op>
+int launch_bwd(const Op& op, int64_t batch, int64_t n1, int64_t n2, const T* G, int64_t ldg, int64_t sG,
+               const OutDesc<T>& rows, const OutDesc<T>& cols, const OutDesc<T>& globs,
+               void* ws, size_t ws_bytes, void* stream) {
+    if (n1 == 0 || n2 == 0 || batch == 0) return 0;
+    const int64_t ntj = cdiv64(n2, BWD_TJ), nti = cdiv64(n1, BWD_TI);
+    if (ws_bytes < bwd_ws_elems<Op>(batch, n1, n2) * sizeof(T) || !ws) return -100;
+    T* P1 = (T*)ws;
+    T* P2 = P1 + batch * ntj * n1 * Op::NR;
+    T* PG = P2 + batch * nti * n2 * Op::NC;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((pairwise_bwd_kernel<T, Op>), dim3((unsigned)ntj, (unsigned)nti, (unsigned)batch), dim3(256),
+                       0, st, op, n1, n2, G, ldg, sG, P1, P2, PG);
+    hipLaunchKernelGGL((reduce_items_kernel<T>), dim3((unsigned)cdiv64(n1 * Op::NR, 256), 1, (unsigned)batch),
+                       dim3(256), 0, st, (const T*)P1, ntj, n1, rows);
+    hipLaunchKernelGGL((reduce_items_kernel<T>), dim3((unsigned)cdiv64(n2 * Op::NC, 256), 1, (unsigned)batch),
+                       dim3(256), 0, st, (const T*)P2, nti, n2, cols);
+    if (globs.nval > 0)
+        hipLaunchKernelGGL((reduce_globals_kernel<T>), dim3((unsigned)batch), dim3(256), 0, st, (const T*)PG,
+                           nti * ntj, globs);
+    return nsgp_launch_status();
+}
+
+template <typename T> OutDesc<T> empty_desc(int nval) {
+    OutDesc<T> d;
+    for (int k = 0; k < 2 * NSGP_MAX_DIM; ++k) {
+        d.ptr[k] = nullptr; d.stride[k] = 0; d.bstride[k] = 0; d.div[k] = nullptr; d.divstride[k] = 0; d.divoff[k] = 0;
+    }
+    d.nval = nval;
+    return d;
+}
+
+// ------------------------------------------------------------------------------------------
+// typed entry points
+// ------------------------------------------------------------------------------------------
+template <typename T, int D>
+int gibbs_fwd_d(const T* x1, const T* x2, const T* l1, const T* l2, int64_t n1, int64_t n2, int Drt, const T* os,
+                const T* diag_add, T* K, int64_t ldk, void* stream) {
+    GibbsOp<T, D> op{x1, x2, l1, l2, n1, n2, Drt, os};
+    return launch_fwd<T>(op, 1, n1, n2, T(0), diag_add, K, ldk, 0, stream);
+}
+
+template <typename T>
+int gibbs_fwd(const T* x1, const T* x2, const T* l1, const T* l2, int64_t n1, int64_t n2, int D, const T* os,
+              const T* diag_add, T* K, int64_t ldk, void* stream) {
+    if (!x1) return -1; if (!x2) return -2; if (!l1) return -3; if (!l2) return -4;
+    if (n1 < 0) return -5; if (n2 < 0) return -6; if (D < 1 || D > NSGP_MAX_DIM) return -7;
+    if (!K && n1 * n2 > 0) return -10; if (ldk < n2) return -11;
+    switch (D) {
+        case 1: return gibbs_fwd_d<T, 1>(x1, x2, l1, l2, n1, n2, D, os, diag_add, K, ldk, stream);
+        case 2: return gibbs_fwd_d<T, 2>(x1, x2, l1, l2, n1, n2, D, os, diag_add, K, ldk, stream);
+        case 3: return gibbs_fwd_d<T, 3>(x1, x2, l1, l2, n1, n2, D, os, diag_add, K, ldk, stream);
+        default: return gibbs_fwd_d<T, 0>(x1, x2, l1, l2, n1, n2, D, os, diag_add, K, ldk, stream);
+    }
+}
+
+template <typename T, int D>
+int gibbs_bwd_d(const T* x1, const T* x2, const T* l1, const T* l2, int64_t n1, int64_t n2, int Drt, const T* os,
+                const T* G, int64_t ldg, T* g_l1, T* g_l2, T* g_x1, T* g_x2, T* g_os, void* ws, size_t wsb,
+                void* stream) {
+    using Op = GibbsOp<T, D>;
+    Op op{x1, x2, l1, l2, n1, n2, Drt, os};
+    constexpr int DM = Op::DM;
+    OutDesc<T> rows = empty_desc<T>(Op::NR), cols = empty_desc<T>(Op::NC), globs = empty_desc<T>(Op::NG);
+    for (int d = 0; d < Drt; ++d) {
+        if (g_l1) { rows.ptr[d] = g_l1 + (int64_t)d * n1; rows.stride[d] = 1; }
+        if (g_x1) { rows.ptr[DM + d] = g_x1 + d; rows.stride[DM + d] = Drt; }
+        if (g_l2) { cols.ptr[d] = g_l2 + (int64_t)d * n2; cols.stride[d] = 1; }
+        if (g_x2) { cols.ptr[DM + d] = g_x2 + d; cols.stride[DM + d] = Drt; }
+    }
+    globs.ptr[0] = g_os;
+    return launch_bwd<T>(op, 1, n1, n2, G, ldg, 0, rows, cols, globs, ws, wsb, stream);
+}
+
+template <typename T>
+int gibbs_bwd(const T* x1, const T* x2, const T* l1, const T* l2, int64_t n1, int64_t n2, int D, const T* os, const T* G,
+              int64_t ldg, T* g_l1, T* g_l2, T* g_x1, T* g_x2, T* g_os, void* ws, size_t wsb, void* stream) {
+    if (!x1) return -1; if (!x2) return -2; if (!l1) return -3; if (!l2) return -4;
+    if (n1 < 0) return -5; if (n2 < 0) return -6; if (D < 1 || D > NSGP_MAX_DIM) return -7;
+    if (!G && n1 * n2 > 0) return -9; if (ldg < n2) return -10;
+    switch (D) {
+        case 1: return gibbs_bwd_d<T, 1>(x1, x2, l1, l2, n1, n2, D, os, G, ldg, g_l1, g_l2, g_x1, g_x2, g_os, ws, wsb, stream);
+        case 2: return gibbs_bwd_d<T, 2>(x1, x2, l1, l2, n1, n2, D, os, G, ldg, g_l1, g_l2, g_x1, g_x2, g_os, ws, wsb, stream);
+        case 3: return gibbs_bwd_d<T, 3>(x1, x2, l1, l2, n1, n2, D, os, G, ldg, g_l1, g_l2, g_x1, g_x2, g_os, ws, wsb, stream);
+        default: return gibbs_bwd_d<T, 0>(x1, x2, l1, l2, n1, n2, D, os, G, ldg, g_l1, g_l2, g_x1, g_x2, g_os, ws, wsb, stream);
+    }
+}
+
+template <typename T, int D>
+int rbf_fwd_d(const T* x1, const T* x2, const T* ls, const T* os, int64_t batch, int64_t n1, int64_t n2, int Drt,
+              int64_t sx1, int64_t sx2, T diag_add, T* K, int64_t ldk, int64_t sK, void* stream) {
+    RbfOp<T, D> op{x1, x2, ls, os, n1, n2, sx1, sx2, Drt};
+    return launch_fwd<T>(op, batch, n1, n2, diag_add, (const T*)nullptr, K, ldk, sK, stream);
+}
+
+template <typename T>
+int rbf_fwd(const T* x1, const T* x2, const T* ls, const T* os, int64_t batch, int64_t n1, int64_t n2, int D,
+            int64_t sx1, int64_t sx2, T diag_add, T* K, int64_t ldk, int64_t sK, void* stream) {
+    if (!x1) return -1; if (!x2) return -2; if (!ls) return -3; if (!os) return -4;
+    if (batch < 0) return -5; if (n1 < 0) return -6; if (n2 < 0) return -7; if (D < 1 || D > NSGP_MAX_DIM) return -8;
+    if (!K && batch * n1 * n2 > 0) return -12; if (ldk < n2) return -13;
+    switch (D) {
+        case 1: return rbf_fwd_d<T, 1>(x1, x2, ls, os, batch, n1, n2, D, sx1, sx2, diag_add, K, ldk, sK, stream);
+        case 2: return rbf_fwd_d<T, 2>(x1, x2, ls, os, batch, n1, n2, D, sx1, sx2, diag_add, K, ldk, sK, stream);
+        case 3: return rbf_fwd_d<T, 3>(x1, x2, ls, os, batch, n1, n2, D, sx1, sx2, diag_add, K, ldk, sK, stream);
+        default: return rbf_fwd_d<T, 0>(x1, x2, ls, os, batch, n1, n2, D, sx1, sx2, diag_add, K, ldk, sK, stream);
+    }
+}
+
+template <typename T, int D>
+int rbf_bwd_d(const T* x1, const T* x2, const T* ls, const T* os, int64_t batch, int64_t n1, int64_t n2, int Drt,
+              int64_t sx1, int64_t sx2, const T* G, int64_t ldg, int64_t sG, T* g_x1, T* g_x2, T* g_ls, T* g_os,
+              void* ws, size_t wsb, void* stream) {
+    using Op = RbfOp<T, D>;
+    Op op{x1, x2, ls, os, n1, n2, sx1, sx2, Drt};
+    constexpr int DM = Op::DM;
+    OutDesc<T> rows = empty_desc<T>(Op::NR), cols = empty_desc<T>(Op::NC), globs = empty_desc<T>(Op::NG);
+    for (int d = 0; d < Drt; ++d) {
+        if (g_x1) { rows.ptr[d] = g_x1 + d; rows.stride[d] = Drt; rows.bstride[d] = n1 * Drt;
+                    rows.div[d] = ls; rows.divstride[d] = Drt; rows.divoff[d] = d; }
+        if (g_x2) { cols.ptr[d] = g_x2 + d; cols.stride[d] = Drt; cols.bstride[d] = n2 * Drt;
+                    cols.div[d] = ls; cols.divstride[d] = Drt; cols.divoff[d] = d; }
+        if (g_ls) { globs.ptr[d] = g_ls + d; globs.bstride[d] = Drt;
+                    globs.div[d] = ls; globs.divstride[d] = Drt; globs.divoff[d] = d; }
+    }
+    if (g_os) { globs.ptr[DM] = g_os; globs.bstride[DM] = 1; }
+    return launch_bwd<T>(op, batch, n1, n2, G, ldg, sG, rows, cols, globs, ws, wsb, stream);
+}
+
+template <typename T>
+int rbf_bwd(const T* x1, const T* x2, const T* ls, const T* os, int64_t batch, int64_t n1, int64_t n2, int D,
+            int64_t sx1, int64_t sx2, const T* G, int64_t ldg, int64_t sG, T* g_x1, T* g_x2, T* g_ls, T* g_os,
+            void* ws, size_t wsb, void* stream) {
+    if (!x1) return -1; if (!x2) return -2; if (!ls) return -3; if (!os) return -4;
+    if (batch < 0) return -5; if (n1 < 0) return -6; if (n2 < 0) return -7; if (D < 1 || D > NSGP_MAX_DIM) return -8;
+    if (!G && batch * n1 * n2 > 0) return -11; if (ldg < n2) return -12;
+    switch (D) {
+        case 1: return rbf_bwd_d<T, 1>(x1, x2, ls, os, batch, n1, n2, D, sx1, sx2, G, ldg, sG, g_x1, g_x2, g_ls, g_os, ws, wsb, stream);
+        case 2: return rbf_bwd_d<T, 2>(x1, x2, ls, os, batch, n1, n2, D, sx1, sx2, G, ldg, sG, g_x1, g_x2, g_ls, g_os, ws, wsb, stream);
+        case 3: return rbf_bwd_d<T, 3>(x1, x2, ls, os, batch, n1, n2, D, sx1, sx2, G, ldg, sG, g_x1, g_x2, g_ls, g_os, ws, wsb, stream);
+        default: return rbf_bwd_d<T, 0>(x1, x2, ls, os, batch, n1, n2, D, sx1, sx2, G, ldg, sG, g_x1, g_x2, g_ls, g_os, ws, wsb, stream);
+    }
+}
+
+template <typename T>
+int ps_fwd(const T* x1, const T* x2, const T* s1, const T* s2, int64_t n1, int64_t n2, T jit, T* K, int64_t ldk,
+           void* stream) {
+    if (!x1) return -1; if (!x2) return -2; if (!s1) return -3; if (!s2) return -4;
+    if (n1 < 0) return -5; if (n2 < 0) return -6; if (!K && n1 * n2 > 0) return -8; if (ldk < n2) return -9;
+    PsOp<T> op{x1, x2, s1, s2, jit};
+    return launch_fwd<T>(op, 1, n1, n2, T(0), (const T*)nullptr, K, ldk, 0, stream);
+}
+
+template <typename T>
+int ps_bwd(const T* x1, const T* x2, const T* s1, const T* s2, int64_t n1, int64_t n2, T jit, const T* G,
+           int64_t ldg, T* g_s1, T* g_s2, void* ws, size_t wsb, void* stream) {
+    if (!x1) return -1; if (!x2) return -2; if (!s1) return -3; if (!s2) return -4;
+    if (n1 < 0) return -5; if (n2 < 0) return -6; if (!G && n1 * n2 > 0) return -8; if (ldg < n2) return -9;
+    using Op = PsOp<T>;
+    Op op{x1, x2, s1, s2, jit};
+    OutDesc<T> rows = empty_desc<T>(4), cols = empty_desc<T>(4), globs = empty_desc<T>(0);
+    for (int k = 0; k < 4; ++k) {
+        if (g_s1) { rows.ptr[k] = g_s1 + k; rows.stride[k] = 4; }
+        if (g_s2) { cols.ptr[k] = g_s2 + k; cols.stride[k] = 4; }
+    }
+    return launch_bwd<T>(op, 1, n1, n2, G, ldg, 0, rows, cols, globs, ws, wsb, stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+int nsgp_gibbs_build_fwd_f32(const float* x1, const float* x2, const float* l1, const float* l2, int64_t n1,
+                             int64_t n2, int D, const float* os, const float* diag_add, float* K, int64_t ldk,
+                             void* stream) {
+    return gibbs_fwd<float>(x1, x2, l1, l2, n1, n2, D, os, diag_add, K, ldk, stream);
+}
+int nsgp_gibbs_build_fwd_f64(const double* x1, const double* x2, const double* l1, const double* l2, int64_t n1,
+                             int64_t n2, int D, const double* os, const double* diag_add, double* K, int64_t ldk,
+                             void* stream) {
+    return gibbs_fwd<double>(x1, x2, l1, l2, n1, n2, D, os, diag_add, K, ldk, stream);
+}
+size_t nsgp_gibbs_build_bwd_workspace(int64_t n1, int64_t n2, int D, int elem_size) {
+    (void)D;                                    // sized for the generic (NSGP_MAX_DIM) functor
+    return bwd_ws_elems<GibbsOp<double, 0>>(1, n1, n2) * (size_t)elem_size + 256;
+}
+int nsgp_gibbs_build_bwd_f32(const float* x1, const float* x2, const float* l1, const float* l2, int64_t n1,
+                             int64_t n2, int D, const float* os, const float* G, int64_t ldg, float* g_l1, float* g_l2,
+                             float* g_x1, float* g_x2, float* g_os, void* ws, size_t wsb, void* stream) {
+    return gibbs_bwd<float>(x1, x2, l1, l2, n1, n2, D, os, G, ldg, g_l1, g_l2, g_x1, g_x2, g_os, ws, wsb, stream);
+}
+int nsgp_gibbs_build_bwd_f64(const double* x1, const double* x2, const double* l1, const double* l2, int64_t n1,
+                             int64_t n2, int D, const double* os, const double* G, int64_t ldg, double* g_l1,
+                             double* g_l2, double* g_x1, double* g_x2, double* g_os, void* ws, size_t wsb,
+                             void* stream) {
+    return gibbs_bwd<double>(x1, x2, l1, l2, n1, n2, D, os, G, ldg, g_l1, g_l2, g_x1, g_x2, g_os, ws, wsb, stream);
+}
+
+int nsgp_rbf_build_fwd_f32(const float* x1, const float* x2, const float* ls, const float* os, int64_t batch,
+                           int64_t n1, int64_t n2, int D, int64_t sx1, int64_t sx2, float diag_add, float* K,
+                           int64_t ldk, int64_t sK, void* stream) {
+    return rbf_fwd<float>(x1, x2, ls, os, batch, n1, n2, D, sx1, sx2, diag_add, K, ldk, sK, stream);
+}
+int nsgp_rbf_build_fwd_f64(const double* x1, const double* x2, const double* ls, const double* os, int64_t batch,
+                           int64_t n1, int64_t n2, int D, int64_t sx1, int64_t sx2, double diag_add, double* K,
+                           int64_t ldk, int64_t sK, void* stream) {
+    return rbf_fwd<double>(x1, x2, ls, os, batch, n1, n2, D, sx1, sx2, diag_add, K, ldk, sK, stream);
+}
+size_t nsgp_rbf_build_bwd_workspace(int64_t batch, int64_t n1, int64_t n2, int D, int elem_size) {
+    (void)D;
+    return bwd_ws_elems<RbfOp<double, 0>>(batch, n1, n2) * (size_t)elem_size + 256;
+}
+int nsgp_rbf_build_bwd_f32(const float* x1, const float* x2, const float* ls, const float* os, int64_t batch,
+                           int64_t n1, int64_t n2, int D, int64_t sx1, int64_t sx2, const float* G, int64_t ldg,
+                           int64_t sG, float* g_x1, float* g_x2, float* g_ls, float* g_os, void* ws, size_t wsb,
+                           void* stream) {
+    return rbf_bwd<float>(x1, x2, ls, os, batch, n1, n2, D, sx1, sx2, G, ldg, sG, g_x1, g_x2, g_ls, g_os, ws, wsb, stream);
+}
+int nsgp_rbf_build_bwd_f64(const double* x1, const double* x2, const double* ls, const double* os, int64_t batch,
+                           int64_t n1, int64_t n2, int D, int64_t sx1, int64_t sx2, const double* G, int64_t ldg,
+                           int64_t sG, double* g_x1, double* g_x2, double* g_ls, double* g_os, void* ws,
+                           size_t wsb, void* stream) {
+    return rbf_bwd<double>(x1, x2, ls, os, batch, n1, n2, D, sx1, sx2, G, ldg, sG, g_x1, g_x2, g_ls, g_os, ws, wsb, stream);
+}
+
+int nsgp_ps2d_build_fwd_f32(const float* x1, const float* x2, const float* s1, const float* s2, int64_t n1,
+                            int64_t n2, float jit, float* K, int64_t ldk, void* stream) {
+    return ps_fwd<float>(x1, x2, s1, s2, n1, n2, jit, K, ldk, stream);
+}
+int nsgp_ps2d_build_fwd_f64(const double* x1, const double* x2, const double* s1, const double* s2, int64_t n1,
+                            int64_t n2, double jit, double* K, int64_t ldk, void* stream) {
+    return ps_fwd<double>(x1, x2, s1, s2, n1, n2, jit, K, ldk, stream);
+}
+size_t nsgp_ps2d_build_bwd_workspace(int64_t n1, int64_t n2, int elem_size) {
+    return bwd_ws_elems<PsOp<double>>(1, n1, n2) * (size_t)elem_size + 256;
+}
+int nsgp_ps2d_build_bwd_f32(const float* x1, const float* x2, const float* s1, const float* s2, int64_t n1,
+                            int64_t n2, float jit, const float* G, int64_t ldg, float* g_s1, float* g_s2, void* ws,
+                            size_t wsb, void* stream) {
+    return ps_bwd<float>(x1, x2, s1, s2, n1, n2, jit, G, ldg, g_s1, g_s2, ws, wsb, stream);
+}
+int nsgp_ps2d_build_bwd_f64(const double* x1, const double* x2, const double* s1, const double* s2, int64_t n1,
+                            int64_t n2, double jit, const double* G, int64_t ldg, double* g_s1, double* g_s2,
+                            void* ws, size_t wsb, void* stream) {
+    return ps_bwd<double>(x1, x2, s1, s2, n1, n2, jit, G, ldg, g_s1, g_s2, ws, wsb, stream);
+}
+
+}  // extern "C"

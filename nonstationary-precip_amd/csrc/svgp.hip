@@ -1,0 +1,369 @@
+// svgp.hip -- K6 SVGP epilogue / DeepGPLayer sampling and K7 ELBO reductions.
+//
+// gpytorch semantics restated (gpytorch itself is absent):
+//   VariationalStrategy.forward : mean = A^T m + mu(x),  var = kxx + 1e-4 + colsum(A o ((S-I)A))
+//                                 with S = Lq Lq^T  ->  colsum(C o C) - colsum(A o A), C = Lq^T A
+//   DeepGPLayer.__call__        : h = mean + sqrt(var) * eps  (diagonal sampling)
+//   GaussianLikelihood.expected_log_prob, VariationalELBO, DeepApproximateMLL, KL(q(u) || N(0,I))
+// driven by models/dgps.py:48-51,92-98 and experiments/deepgp_spatial_bench.py:61,84-88.
+// All of these are HBM-bound streaming passes over (M x n) or (S x n) data.
+#include "common.h"
+
+namespace {
+
+// ---- colstats: mean[b,j] = sum_k A m ; var[b,j] = base[b] + sum_k (C^2 - A^2) ------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ A, const T* __restrict__ C,
+                                                       const T* __restrict__ m, const T* __restrict__ base,
+                                                       int64_t M, int64_t n, T* __restrict__ mean,
+                                                       T* __restrict__ var) {
+    __shared__ T sm[4][64], sv[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t b = blockIdx.y, j = (int64_t)blockIdx.x * 64 + lane;
+    const T* Ab = A + b * M * n;
+    const T* Cb = C + b * M * n;
+    const T* mb = m + b * M;
+    T am = T(0), av = T(0);
+    if (j < n) {
+        const int64_t kq = (M + 3) / 4;
+        const int64_t k0 = w * kq, k1 = (k0 + kq) < M ? (k0 + kq) : M;
+        for (int64_t k = k0; k < k1; ++k) {
+            const T a = Ab[k * n + j], c = Cb[k * n + j];
+            am += a * mb[k];
+            av += c * c - a * a;
+        }
+    }
+    sm[w][lane] = am; sv[w][lane] = av;
+    __syncthreads();
+    if (w == 0 && j < n) {
+        mean[b * n + j] = sm[0][lane] + sm[1][lane] + sm[2][lane] + sm[3][lane];
+        var[b * n + j] = base[b] + (sv[0][lane] + sv[1][lane] + sv[2][lane] + sv[3][lane]);
+    }
+}
+
+// ---- colstats backward: one block per (row k, batch b) ------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colstats_bwd_kernel(const T* __restrict__ A, const T* __restrict__ C,
+                                                           const T* __restrict__ m, const T* __restrict__ gmean,
+                                                           const T* __restrict__ gvar, int64_t M, int64_t n,
+                                                           T* __restrict__ Abar, T* __restrict__ C2,
+                                                           T* __restrict__ mbar) {
+    __shared__ T lds[4];
+    const int64_t b = blockIdx.y, k = blockIdx.x;
+    const int64_t off = (b * M + k) * n;
+    const T mk = m[b * M + k];
+    const T* gm = gmean + b * n;
+    const T* gv = gvar + b * n;
+    T acc = T(0);
+    for (int64_t j = threadIdx.x; j < n; j += 256) {
+        const T a = A[off + j], g1 = gm[j], g2 = T(2) * gv[j];
+        acc += a * g1;
+        Abar[off + j] = mk * g1 - g2 * a;
+        C2[off + j] = g2 * C[off + j];
+    }
+    acc = block_sum_256(acc, lds);
+    if (threadIdx.x == 0) mbar[b * M + k] = acc;
+}
+
+// ---- sampling ------------------------------------------------------------------------------------
+template <typename T>
+__global__ void sample_fwd_kernel(const T* __restrict__ mean, const T* __restrict__ var, const T* __restrict__ eps,
+                                  int64_t S, int64_t ns, int64_t n, int64_t b, T* __restrict__ h) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= S * n * b) return;
+    const int64_t c = idx % b, i = (idx / b) % n, s = idx / (b * n);
+    const int64_t sp = ns == 1 ? 0 : s;
+    const int64_t q = (c * ns + sp) * n + i;
+    h[idx] = mean[q] + t_sqrt(var[q]) * eps[idx];
+}
+
+template <typename T>
+__global__ void sample_bwd_kernel(const T* __restrict__ var, const T* __restrict__ eps, const T* __restrict__ gh,
+                                  int64_t S, int64_t ns, int64_t n, int64_t b, T* __restrict__ gmean,
+                                  T* __restrict__ gvar) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= b * ns * n) return;
+    const int64_t i = q % n, sp = (q / n) % ns, c = q / (n * ns);
+    const T hs = T(0.5) / t_sqrt(var[q]);
+    T gm = T(0), gv = T(0);
+    const int64_t s0 = ns == 1 ? 0 : sp, s1 = ns == 1 ? S : sp + 1;
+    for (int64_t s = s0; s < s1; ++s) {
+        const int64_t idx = (s * n + i) * b + c;
+        const T g = gh[idx];
+        gm += g;
+        gv += g * eps[idx] * hs;
+    }
+    gmean[q] = gm;
+    gvar[q] = gv;
+}
+
+// ---- generic two-stage sum ---------------------------------------------------------------------
+constexpr int RED_BLOCKS = 512;
+
+template <typename T>
+__global__ __launch_bounds__(256) void reduce_final_kernel(const T* __restrict__ part, int64_t nparts, int64_t nout,
+                                                           T scale, T add, T* __restrict__ out) {
+    __shared__ T lds[4];
+    const int64_t o = blockIdx.x;
+    if (o >= nout) return;
+    T s = T(0);
+    for (int64_t t = threadIdx.x; t < nparts; t += 256) s += part[o * nparts + t];
+    s = block_sum_256(s, lds);
+    if (threadIdx.x == 0) out[o] = scale * s + add;
+}
+
+// ---- gaussian expected log-likelihood -----------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gauss_ell_part_kernel(const T* __restrict__ y, const T* __restrict__ mu,
+                                                             const T* __restrict__ v, const T* __restrict__ noise,
+                                                             int64_t S, int64_t n, int want_gnoise,
+                                                             T* __restrict__ part) {
+    __shared__ T lds[4];
+    const T s2 = noise[0];
+    const T is2 = T(1) / s2, ls2 = t_log(s2);
+    const T l2pi = T(1.8378770664093454835606594728112);
+    T acc = T(0);
+    const int64_t tot = S * n;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < tot; idx += (int64_t)gridDim.x * 256) {
+        const T d = y[idx % n] - mu[idx];
+        const T e = d * d + v[idx];
+        acc += want_gnoise ? T(0.5) * (e * is2 * is2 - is2) : T(-0.5) * (e * is2 + ls2 + l2pi);
+    }
+    acc = block_sum_256(acc, lds);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+
+template <typename T>
+__global__ void gauss_ell_bwd_kernel(const T* __restrict__ y, const T* __restrict__ mu, const T* __restrict__ noise,
+                                     int64_t S, int64_t n, T coef, T* __restrict__ gmu, T* __restrict__ gv) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= S * n) return;
+    const T is2 = T(1) / noise[0];
+    gmu[idx] = coef * (y[idx % n] - mu[idx]) * is2;
+    gv[idx] = T(-0.5) * coef * is2;
+}
+
+// ---- KL(q(u) || N(0, I)) --------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void kl_part_kernel(const T* __restrict__ m, const T* __restrict__ Lq, int64_t M,
+                                                      T* __restrict__ part) {
+    __shared__ T lds[4];
+    const int64_t b = blockIdx.y;
+    const T* L = Lq + b * M * M;
+    T acc = T(0);
+    const int64_t tot = M * M;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < tot; idx += (int64_t)gridDim.x * 256) {
+        const int64_t i = idx / M, j = idx % M;
+        if (j <= i) {
+            const T l = L[idx];
+            acc += l * l;
+            if (i == j) acc += m[b * M + i] * m[b * M + i] - T(2) * t_log(l < T(0) ? -l : l);
+        }
+    }
+    acc = block_sum_256(acc, lds);
+    if (threadIdx.x == 0) part[b * gridDim.x + blockIdx.x] = acc;
+}
+
+template <typename T>
+__global__ void kl_bwd_kernel(const T* __restrict__ m, const T* __restrict__ Lq, int64_t batch, int64_t M, T gout,
+                              T* __restrict__ gm, T* __restrict__ gLq) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= batch * M * M) return;
+    const int64_t e = idx % (M * M), b = idx / (M * M);
+    const int64_t i = e / M, j = e % M;
+    T g = T(0);
+    if (j <= i) {
+        const T l = Lq[idx];
+        g = gout * (i == j ? l - T(1) / l : l);
+        if (i == j) gm[b * M + i] = gout * m[b * M + i];
+    }
+    gLq[idx] = g;
+}
+
+template <typename T>
+int colstats_impl(const T* A, const T* C, const T* m, const T* base, int64_t batch, int64_t M, int64_t n, T* mean,
+                  T* var, void* stream) {
+    if (!A) return -1; if (!C) return -2; if (!m) return -3; if (!base) return -4;
+    if (batch < 0) return -5; if (M < 0) return -6; if (n < 0) return -7; if (!mean) return -8; if (!var) return -9;
+    if (batch == 0 || n == 0) return 0;
+    hipLaunchKernelGGL((colstats_kernel<T>), dim3((unsigned)cdiv64(n, 64), (unsigned)batch), dim3(256), 0,
+                       (hipStream_t)stream, A, C, m, base, M, n, mean, var);
+    return nsgp_launch_status();
+}
+
+template <typename T>
+int colstats_bwd_impl(const T* A, const T* C, const T* m, const T* gmean, const T* gvar, int64_t batch, int64_t M,
+                      int64_t n, T* Abar, T* C2, T* mbar, void* stream) {
+    if (!A) return -1; if (!C) return -2; if (!m) return -3; if (!gmean) return -4; if (!gvar) return -5;
+    if (batch < 0) return -6; if (M < 0) return -7; if (n < 0) return -8;
+    if (!Abar) return -9; if (!C2) return -10; if (!mbar) return -11;
+    if (batch == 0 || M == 0) return 0;
+    hipLaunchKernelGGL((colstats_bwd_kernel<T>), dim3((unsigned)M, (unsigned)batch), dim3(256), 0, (hipStream_t)stream,
+                       A, C, m, gmean, gvar, M, n, Abar, C2, mbar);
+    return nsgp_launch_status();
+}
+
+template <typename T>
+int sample_fwd_impl(const T* mean, const T* var, const T* eps, int64_t S, int64_t ns, int64_t n, int64_t b, T* h,
+                    void* stream) {
+    if (!mean) return -1; if (!var) return -2; if (!eps) return -3;
+    if (S < 0) return -4; if (ns != 1 && ns != S) return -5; if (n < 0) return -6; if (b < 0) return -7; if (!h) return -8;
+    const int64_t tot = S * n * b;
+    if (tot == 0) return 0;
+    hipLaunchKernelGGL((sample_fwd_kernel<T>), dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, (hipStream_t)stream,
+                       mean, var, eps, S, ns, n, b, h);
+    return nsgp_launch_status();
+}
+
+template <typename T>
+int sample_bwd_impl(const T* var, const T* eps, const T* gh, int64_t S, int64_t ns, int64_t n, int64_t b, T* gmean,
+                    T* gvar, void* stream) {
+    if (!var) return -1; if (!eps) return -2; if (!gh) return -3;
+    if (S < 0) return -4; if (ns != 1 && ns != S) return -5; if (n < 0) return -6; if (b < 0) return -7;
+    if (!gmean) return -8; if (!gvar) return -9;
+    const int64_t tot = b * ns * n;
+    if (tot == 0) return 0;
+    hipLaunchKernelGGL((sample_bwd_kernel<T>), dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, (hipStream_t)stream,
+                       var, eps, gh, S, ns, n, b, gmean, gvar);
+    return nsgp_launch_status();
+}
+
+template <typename T>
+int gauss_fwd_impl(const T* y, const T* mu, const T* v, const T* noise, int64_t S, int64_t n, T scale, T* out,
+                   void* ws, size_t wsb, void* stream) {
+    if (!y) return -1; if (!mu) return -2; if (!v) return -3; if (!noise) return -4;
+    if (S < 0) return -5; if (n < 0) return -6; if (!out) return -8;
+    if (!ws || wsb < RED_BLOCKS * sizeof(T)) return -9;
+    hipStream_t st = (hipStream_t)stream;
+    int64_t nblk = cdiv64(S * n, 256); if (nblk > RED_BLOCKS) nblk = RED_BLOCKS; if (nblk < 1) nblk = 1;
+    hipLaunchKernelGGL((gauss_ell_part_kernel<T>), dim3((unsigned)nblk), dim3(256), 0, st, y, mu, v, noise, S, n, 0,
+                       (T*)ws);
+    hipLaunchKernelGGL((reduce_final_kernel<T>), dim3(1), dim3(256), 0, st, (const T*)ws, nblk, (int64_t)1, scale,
+                       T(0), out);
+    return nsgp_launch_status();
+}
+
+template <typename T>
+int gauss_bwd_impl(const T* y, const T* mu, const T* v, const T* noise, int64_t S, int64_t n, T scale, T gout, T* gmu,
+                   T* gv, T* gnoise, void* ws, size_t wsb, void* stream) {
+    if (!y) return -1; if (!mu) return -2; if (!v) return -3; if (!noise) return -4;
+    if (S < 0) return -5; if (n < 0) return -6; if (!gmu) return -9; if (!gv) return -10;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t tot = S * n;
+    if (tot > 0)
+        hipLaunchKernelGGL((gauss_ell_bwd_kernel<T>), dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, st, y, mu, noise,
+                           S, n, gout * scale, gmu, gv);
+    if (gnoise) {
+        if (!ws || wsb < RED_BLOCKS * sizeof(T)) return -12;
+        int64_t nblk = cdiv64(tot, 256); if (nblk > RED_BLOCKS) nblk = RED_BLOCKS; if (nblk < 1) nblk = 1;
+        hipLaunchKernelGGL((gauss_ell_part_kernel<T>), dim3((unsigned)nblk), dim3(256), 0, st, y, mu, v, noise, S, n,
+                           1, (T*)ws);
+        hipLaunchKernelGGL((reduce_final_kernel<T>), dim3(1), dim3(256), 0, st, (const T*)ws, nblk, (int64_t)1,
+                           gout * scale, T(0), gnoise);
+    }
+    return nsgp_launch_status();
+}
+
+template <typename T>
+int kl_fwd_impl(const T* m, const T* Lq, int64_t batch, int64_t M, T* out, void* ws, size_t wsb, void* stream) {
+    if (!m) return -1; if (!Lq) return -2; if (batch < 0) return -3; if (M < 0) return -4; if (!out) return -5;
+    if (batch == 0) return 0;
+    int64_t nblk = cdiv64(M * M, 1024); if (nblk > 256) nblk = 256; if (nblk < 1) nblk = 1;
+    if (!ws || wsb < (size_t)(batch * nblk) * sizeof(T)) return -6;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((kl_part_kernel<T>), dim3((unsigned)nblk, (unsigned)batch), dim3(256), 0, st, m, Lq, M, (T*)ws);
+    hipLaunchKernelGGL((reduce_final_kernel<T>), dim3((unsigned)batch), dim3(256), 0, st, (const T*)ws, nblk, batch,
+                       T(0.5), T(-0.5) * T(M), out);
+    return nsgp_launch_status();
+}
+
+template <typename T>
+int kl_bwd_impl(const T* m, const T* Lq, int64_t batch, int64_t M, T gout, T* gm, T* gLq, void* stream) {
+    if (!m) return -1; if (!Lq) return -2; if (batch < 0) return -3; if (M < 0) return -4; if (!gm) return -6;
+    if (!gLq) return -7;
+    const int64_t tot = batch * M * M;
+    if (tot == 0) return 0;
+    hipLaunchKernelGGL((kl_bwd_kernel<T>), dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, (hipStream_t)stream, m, Lq,
+                       batch, M, gout, gm, gLq);
+    return nsgp_launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t nsgp_reduce_workspace(int64_t n_elems, int elem_size) {
+    (void)n_elems;
+    return (size_t)65536 * elem_size;       // covers RED_BLOCKS partials and 256 x batch(<=256) KL partials
+}
+
+int nsgp_svgp_colstats_f32(const float* A, const float* C, const float* m, const float* base, int64_t batch,
+                           int64_t M, int64_t n, float* mean, float* var, void* stream) {
+    return colstats_impl<float>(A, C, m, base, batch, M, n, mean, var, stream);
+}
+int nsgp_svgp_colstats_f64(const double* A, const double* C, const double* m, const double* base, int64_t batch,
+                           int64_t M, int64_t n, double* mean, double* var, void* stream) {
+    return colstats_impl<double>(A, C, m, base, batch, M, n, mean, var, stream);
+}
+int nsgp_svgp_colstats_bwd_f32(const float* A, const float* C, const float* m, const float* gmean,
+                               const float* gvar, int64_t batch, int64_t M, int64_t n, float* Abar, float* C2,
+                               float* mbar, void* stream) {
+    return colstats_bwd_impl<float>(A, C, m, gmean, gvar, batch, M, n, Abar, C2, mbar, stream);
+}
+int nsgp_svgp_colstats_bwd_f64(const double* A, const double* C, const double* m, const double* gmean,
+                               const double* gvar, int64_t batch, int64_t M, int64_t n, double* Abar, double* C2,
+                               double* mbar, void* stream) {
+    return colstats_bwd_impl<double>(A, C, m, gmean, gvar, batch, M, n, Abar, C2, mbar, stream);
+}
+int nsgp_dgp_sample_fwd_f32(const float* mean, const float* var, const float* eps, int64_t S, int64_t ns, int64_t n,
+                            int64_t b, float* h, void* stream) {
+    return sample_fwd_impl<float>(mean, var, eps, S, ns, n, b, h, stream);
+}
+int nsgp_dgp_sample_bwd_f32(const float* var, const float* eps, const float* gh, int64_t S, int64_t ns, int64_t n,
+                            int64_t b, float* gmean, float* gvar, void* stream) {
+    return sample_bwd_impl<float>(var, eps, gh, S, ns, n, b, gmean, gvar, stream);
+}
+int nsgp_dgp_sample_fwd_f64(const double* mean, const double* var, const double* eps, int64_t S, int64_t ns,
+                            int64_t n, int64_t b, double* h, void* stream) {
+    return sample_fwd_impl<double>(mean, var, eps, S, ns, n, b, h, stream);
+}
+int nsgp_dgp_sample_bwd_f64(const double* var, const double* eps, const double* gh, int64_t S, int64_t ns, int64_t n,
+                            int64_t b, double* gmean, double* gvar, void* stream) {
+    return sample_bwd_impl<double>(var, eps, gh, S, ns, n, b, gmean, gvar, stream);
+}
+int nsgp_gauss_ell_fwd_f32(const float* y, const float* mu, const float* v, const float* noise, int64_t S, int64_t n,
+                           float scale, float* out, void* ws, size_t wsb, void* stream) {
+    return gauss_fwd_impl<float>(y, mu, v, noise, S, n, scale, out, ws, wsb, stream);
+}
+int nsgp_gauss_ell_bwd_f32(const float* y, const float* mu, const float* v, const float* noise, int64_t S, int64_t n,
+                           float scale, float gout, float* gmu, float* gv, float* gnoise, void* ws, size_t wsb,
+                           void* stream) {
+    return gauss_bwd_impl<float>(y, mu, v, noise, S, n, scale, gout, gmu, gv, gnoise, ws, wsb, stream);
+}
+int nsgp_gauss_ell_fwd_f64(const double* y, const double* mu, const double* v, const double* noise, int64_t S,
+                           int64_t n, double scale, double* out, void* ws, size_t wsb, void* stream) {
+    return gauss_fwd_impl<double>(y, mu, v, noise, S, n, scale, out, ws, wsb, stream);
+}
+int nsgp_gauss_ell_bwd_f64(const double* y, const double* mu, const double* v, const double* noise, int64_t S,
+                           int64_t n, double scale, double gout, double* gmu, double* gv, double* gnoise, void* ws,
+                           size_t wsb, void* stream) {
+    return gauss_bwd_impl<double>(y, mu, v, noise, S, n, scale, gout, gmu, gv, gnoise, ws, wsb, stream);
+}
+int nsgp_kl_whitened_fwd_f32(const float* m, const float* Lq, int64_t batch, int64_t M, float* out, void* ws,
+                             size_t wsb, void* stream) {
+    return kl_fwd_impl<float>(m, Lq, batch, M, out, ws, wsb, stream);
+}
+int nsgp_kl_whitened_bwd_f32(const float* m, const float* Lq, int64_t batch, int64_t M, float gout, float* gm,
+                             float* gLq, void* stream) {
+    return kl_bwd_impl<float>(m, Lq, batch, M, gout, gm, gLq, stream);
+}
+int nsgp_kl_whitened_fwd_f64(const double* m, const double* Lq, int64_t batch, int64_t M, double* out, void* ws,
+                             size_t wsb, void* stream) {
+    return kl_fwd_impl<double>(m, Lq, batch, M, out, ws, wsb, stream);
+}
+int nsgp_kl_whitened_bwd_f64(const double* m, const double* Lq, int64_t batch, int64_t M, double gout, double* gm,
+                             double* gLq, void* stream) {
+    return kl_bwd_impl<double>(m, Lq, batch, M, gout, gm, gLq, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,648 @@
+"""Device ops: thin, checked wrappers over the C ABI (include/nsgp.h) + torch.autograd.Functions.
+
+Every function here requires CUDA (ROCm) tensors and runs a hand-written gfx950 kernel on torch's
+current stream; torch only owns memory, streams and the autograd graph edges.  There is no CPU or
+eager fallback: a CPU tensor or a missing library raises `BackendError`.
+
+Raw ops (no autograd) are lower-case functions returning new tensors; autograd entry points are the
+`*Fn` classes and the lower-case convenience wrappers at the bottom (`gibbs_kernel`, `rbf_kernel`,
+`ps2d_kernel`, `matmul`, `chol_inv`, ...).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import BackendError
+
+GEMM_A_LOWER, GEMM_A_UPPER, GEMM_B_LOWER, GEMM_B_UPPER, GEMM_C_LOWER, GEMM_NO_SPLITK = 1, 2, 4, 8, 16, 32
+
+
+# --------------------------------------------------------------------------------------------
+# plumbing
+# --------------------------------------------------------------------------------------------
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _sfx(t):
+    if t.dtype == torch.float32:
+        return 'f32'
+    if t.dtype == torch.float64:
+        return 'f64'
+    raise BackendError(f'nsgp kernels compute in float32/float64, got {t.dtype}')
+
+
+def _chk(*ts):
+    """All tensors on the same CUDA device, same floating dtype."""
+    first = None
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise BackendError('nsgp ops need CUDA (ROCm) tensors: the HIP backend is the only backend '
+                               '(no CPU fallback).  Move the model/data to the GPU.')
+        if first is None:
+            first = t
+        elif t.dtype != first.dtype or t.device != first.device:
+            raise BackendError(f'mixed dtype/device: {t.dtype}/{t.device} vs {first.dtype}/{first.device}')
+    _sfx(first)
+    return first
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def _scalar_dev(v, like):
+    """Host number or tensor -> 1-element device tensor of like's dtype (no sync)."""
+    if torch.is_tensor(v):
+        return v.detach().reshape(1).to(device=like.device, dtype=like.dtype)
+    return torch.full((1,), float(v), dtype=like.dtype, device=like.device)
+
+
+# --------------------------------------------------------------------------------------------
+# K1 Gibbs
+# --------------------------------------------------------------------------------------------
+def _gibbs_args(x1, x2, ell1, ell2):
+    ref = _chk(x1, x2, ell1, ell2)
+    if x1.dim() != 2 or x2.dim() != 2 or ell1.dim() != 2 or ell2.dim() != 2:
+        raise BackendError('gibbs_build: x:(n,D), ell:(D,n) expected')
+    n1, D = x1.shape
+    n2 = x2.shape[0]
+    if x2.shape[1] != D or ell1.shape != (D, n1) or ell2.shape != (D, n2):
+        raise BackendError(f'gibbs_build: shape mismatch x1{tuple(x1.shape)} x2{tuple(x2.shape)} '
+                           f'ell1{tuple(ell1.shape)} ell2{tuple(ell2.shape)}')
+    return ref, n1, n2, D
+
+
+def gibbs_build(x1, x2, ell1, ell2, outputscale=None, diag_add=None):
+    """K = os * Gibbs(x1,x2; ell1,ell2) (+ diag_add on the diagonal).  models/gibbs_kernels.py:154-162."""
+    ref, n1, n2, D = _gibbs_args(x1, x2, ell1, ell2)
+    x1, x2, ell1, ell2 = _c(x1), _c(x2), _c(ell1), _c(ell2)
+    os_ = None if outputscale is None else _scalar_dev(outputscale, ref)
+    da = None if diag_add is None else _scalar_dev(diag_add, ref)
+    K = torch.empty((n1, n2), dtype=ref.dtype, device=ref.device)
+    _lib.call(f'nsgp_gibbs_build_fwd_{_sfx(ref)}', _p(x1), _p(x2), _p(ell1), _p(ell2), n1, n2, D,
+              _p(os_), _p(da), _p(K), n2, _stream())
+    return K
+
+
+def gibbs_build_bwd(x1, x2, ell1, ell2, outputscale, G, need_x=False, need_os=True):
+    ref, n1, n2, D = _gibbs_args(x1, x2, ell1, ell2)
+    _chk(ref, G)
+    if G.shape != (n1, n2):
+        raise BackendError('gibbs_build_bwd: G shape')
+    x1, x2, ell1, ell2, G = _c(x1), _c(x2), _c(ell1), _c(ell2), _c(G)
+    os_ = None if outputscale is None else _scalar_dev(outputscale, ref)
+    g_l1, g_l2 = torch.empty_like(ell1), torch.empty_like(ell2)
+    g_x1 = torch.empty_like(x1) if need_x else None
+    g_x2 = torch.empty_like(x2) if need_x else None
+    g_os = torch.empty(1, dtype=ref.dtype, device=ref.device) if need_os else None
+    lib = _lib.load()
+    wsb = lib.nsgp_gibbs_build_bwd_workspace(n1, n2, D, ref.element_size())
+    ws = _ws(wsb, ref.device)
+    _lib.call(f'nsgp_gibbs_build_bwd_{_sfx(ref)}', _p(x1), _p(x2), _p(ell1), _p(ell2), n1, n2, D, _p(os_),
+              _p(G), n2, _p(g_l1), _p(g_l2), _p(g_x1), _p(g_x2), _p(g_os), _p(ws), ws.numel(), _stream())
+    return g_l1, g_l2, g_x1, g_x2, g_os
+
+
+# --------------------------------------------------------------------------------------------
+# K2 RBF-ARD (batched)
+# --------------------------------------------------------------------------------------------
+def _rbf_args(x1, x2, ls, os_):
+    ref = _chk(x1, x2, ls, os_)
+    if ls.dim() == 1:
+        ls = ls.unsqueeze(0)
+    os_ = os_.reshape(-1)
+    batch, D = ls.shape
+    if os_.shape[0] != batch:
+        raise BackendError('rbf_build: os must be (batch,)')
+
+    def prep(x):
+        if x.dim() == 2:
+            if x.shape[1] != D:
+                raise BackendError('rbf_build: x last dim != D')
+            return _c(x), x.shape[0], 0
+        if x.dim() == 3 and x.shape[0] == batch and x.shape[2] == D:
+            x = _c(x)
+            return x, x.shape[1], x.shape[1] * D
+        raise BackendError(f'rbf_build: x shape {tuple(x.shape)} vs batch {batch}, D {D}')
+    x1, n1, sx1 = prep(x1)
+    x2, n2, sx2 = prep(x2)
+    return ref, x1, x2, _c(ls), _c(os_), batch, n1, n2, D, sx1, sx2
+
+
+def rbf_build(x1, x2, ls, os_, diag_add=0.0):
+    """K[b] = os[b] * exp(-0.5 |(x1-x2)/ls[b]|^2) (+diag_add I).  x:(n,D) shared or (batch,n,D)."""
+    ref, x1, x2, ls, os_, batch, n1, n2, D, sx1, sx2 = _rbf_args(x1, x2, ls, os_)
+    K = torch.empty((batch, n1, n2), dtype=ref.dtype, device=ref.device)
+    _lib.call(f'nsgp_rbf_build_fwd_{_sfx(ref)}', _p(x1), _p(x2), _p(ls), _p(os_), batch, n1, n2, D, sx1, sx2,
+              float(diag_add), _p(K), n2, n1 * n2, _stream())
+    return K
+
+
+def rbf_build_bwd(x1, x2, ls, os_, G, need_x1=True, need_x2=True):
+    """Returns g_x1:(batch,n1,D) g_x2:(batch,n2,D) (per-batch, caller sums if x was shared) g_ls, g_os."""
+    ref, x1, x2, ls, os_, batch, n1, n2, D, sx1, sx2 = _rbf_args(x1, x2, ls, os_)
+    _chk(ref, G)
+    G = _c(G).reshape(batch, n1, n2)
+    g_x1 = torch.empty((batch, n1, D), dtype=ref.dtype, device=ref.device) if need_x1 else None
+    g_x2 = torch.empty((batch, n2, D), dtype=ref.dtype, device=ref.device) if need_x2 else None
+    g_ls = torch.empty((batch, D), dtype=ref.dtype, device=ref.device)
+    g_os = torch.empty((batch,), dtype=ref.dtype, device=ref.device)
+    lib = _lib.load()
+    ws = _ws(lib.nsgp_rbf_build_bwd_workspace(batch, n1, n2, D, ref.element_size()), ref.device)
+    _lib.call(f'nsgp_rbf_build_bwd_{_sfx(ref)}', _p(x1), _p(x2), _p(ls), _p(os_), batch, n1, n2, D, sx1, sx2,
+              _p(G), n2, n1 * n2, _p(g_x1), _p(g_x2), _p(g_ls), _p(g_os), _p(ws), ws.numel(), _stream())
+    return g_x1, g_x2, g_ls, g_os
+
+
+# --------------------------------------------------------------------------------------------
+# K3 Paciorek-Schervish (D = 2)
+# --------------------------------------------------------------------------------------------
+def _ps_args(x1, x2, s1, s2):
+    ref = _chk(x1, x2, s1, s2)
+    n1, n2 = x1.shape[0], x2.shape[0]
+    if x1.shape != (n1, 2) or x2.shape != (n2, 2) or s1.shape != (n1, 2, 2) or s2.shape != (n2, 2, 2):
+        raise BackendError('ps2d_build: x:(n,2), sigma:(n,2,2) expected')
+    return ref, n1, n2
+
+
+def ps2d_build(x1, x2, s1, s2, jitter=1e-5):
+    ref, n1, n2 = _ps_args(x1, x2, s1, s2)
+    x1, x2, s1, s2 = _c(x1), _c(x2), _c(s1), _c(s2)
+    K = torch.empty((n1, n2), dtype=ref.dtype, device=ref.device)
+    _lib.call(f'nsgp_ps2d_build_fwd_{_sfx(ref)}', _p(x1), _p(x2), _p(s1), _p(s2), n1, n2, float(jitter), _p(K), n2,
+              _stream())
+    return K
+
+
+def ps2d_build_bwd(x1, x2, s1, s2, jitter, G):
+    ref, n1, n2 = _ps_args(x1, x2, s1, s2)
+    _chk(ref, G)
+    x1, x2, s1, s2, G = _c(x1), _c(x2), _c(s1), _c(s2), _c(G)
+    g1, g2 = torch.empty_like(s1), torch.empty_like(s2)
+    lib = _lib.load()
+    ws = _ws(lib.nsgp_ps2d_build_bwd_workspace(n1, n2, ref.element_size()), ref.device)
+    _lib.call(f'nsgp_ps2d_build_bwd_{_sfx(ref)}', _p(x1), _p(x2), _p(s1), _p(s2), n1, n2, float(jitter), _p(G), n2,
+              _p(g1), _p(g2), _p(ws), ws.numel(), _stream())
+    return g1, g2
+
+
+# --------------------------------------------------------------------------------------------
+# MFMA GEMM
+# --------------------------------------------------------------------------------------------
+def _mat_view(t, trans):
+    """Return (tensor, rows, cols, row_stride, col_stride, batch, batch_stride) of op(t) without copying
+    when one of the two trailing strides is 1; otherwise make it contiguous."""
+    if t.dim() not in (2, 3):
+        raise BackendError('gemm: operands must be 2-D or 3-D (batched)')
+    sr, sc = t.stride(-2), t.stride(-1)
+    ok = (sr == 1 or sc == 1) and (t.dim() == 2 or t.shape[0] == 1 or t.stride(0) >= 0)
+    if t.shape[-1] == 1 and sr != 1:
+        sc = 1
+    if t.shape[-2] == 1 and sc != 1:
+        sr = 1
+    if not ok or not (sr == 1 or sc == 1):
+        t = t.contiguous()
+        sr, sc = t.stride(-2), t.stride(-1)
+    r, c = t.shape[-2], t.shape[-1]
+    if trans:
+        r, c, sr, sc = c, r, sc, sr
+    nb = t.shape[0] if t.dim() == 3 else 1
+    sb = t.stride(0) if t.dim() == 3 else 0
+    return t, r, c, sr, sc, nb, sb
+
+
+def gemm(A, B, ta=False, tb=False, alpha=1.0, beta=0.0, out=None, flags=0):
+    """out = alpha * op(A) @ op(B) + beta * out on the matrix cores.  2-D or batched 3-D operands
+    (a 2-D operand broadcasts against a 3-D one)."""
+    ref = _chk(A, B, out)
+    A, M, K, sam, sak, nba, sba = _mat_view(A, ta)
+    B, K2, N, sbk, sbn, nbb, sbb = _mat_view(B, tb)
+    if K != K2:
+        raise BackendError(f'gemm: inner dims {K} vs {K2}')
+    nb = max(nba, nbb)
+    if nba not in (1, nb) or nbb not in (1, nb):
+        raise BackendError('gemm: batch mismatch')
+    if nba == 1:
+        sba = 0
+    if nbb == 1:
+        sbb = 0
+    batched = A.dim() == 3 or B.dim() == 3
+    shape = (nb, M, N) if batched else (M, N)
+    if out is None:
+        if beta != 0.0:
+            raise BackendError('gemm: beta != 0 needs out')
+        out = torch.empty(shape, dtype=ref.dtype, device=ref.device)
+    else:
+        if tuple(out.shape) != shape or not out.is_contiguous():
+            raise BackendError(f'gemm: out must be contiguous {shape}, got {tuple(out.shape)}')
+    lib = _lib.load()
+    wsb = 0 if (flags & GEMM_NO_SPLITK) else lib.nsgp_gemm_workspace(M, N, K, nb, 1, ref.element_size())
+    ws = _ws(wsb, ref.device) if wsb else None
+    _lib.call(f'nsgp_gemm_{_sfx(ref)}', M, N, K, float(alpha), _p(A), sam, sak, sba, 0, _p(B), sbk, sbn, sbb, 0,
+              float(beta), _p(out), N, M * N, 0, nb, 1, int(flags), _p(ws), ws.numel() if ws is not None else 0,
+              _stream())
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# K4 / K5 Cholesky, triangular inverse
+# --------------------------------------------------------------------------------------------
+def potrf(A, check=False, overwrite=False):
+    """Lower Cholesky factor of a (batched) SPD matrix; returns (L, info) with info an int32 device
+    tensor (LAPACK convention).  `check=True` syncs and raises on failure; `overwrite=True` factors a
+    contiguous input in place."""
+    ref = _chk(A)
+    if A.dim() not in (2, 3) or A.shape[-1] != A.shape[-2]:
+        raise BackendError('potrf: square (batched) matrix expected')
+    L = A if (overwrite and A.is_contiguous()) else A.contiguous().clone()
+    n = L.shape[-1]
+    batch = L.shape[0] if L.dim() == 3 else 1
+    info = torch.zeros(batch, dtype=torch.int32, device=ref.device)
+    lib = _lib.load()
+    ws = _ws(lib.nsgp_potrf_workspace(n, batch, ref.element_size()), ref.device)
+    _lib.call(f'nsgp_potrf_{_sfx(ref)}', _p(L), n, n, n * n, batch, _p(info), _p(ws), ws.numel(), _stream())
+    if check:
+        bad = int(info.max().item())
+        if bad:
+            raise BackendError(f'potrf: leading minor {bad} is not positive definite')
+    return L, info
+
+
+def trtri(L):
+    """X = L^-1 for a (batched) lower-triangular L (strict upper of L ignored, of X zero)."""
+    ref = _chk(L)
+    if L.dim() not in (2, 3) or L.shape[-1] != L.shape[-2]:
+        raise BackendError('trtri: square (batched) matrix expected')
+    L = _c(L)
+    n = L.shape[-1]
+    batch = L.shape[0] if L.dim() == 3 else 1
+    X = torch.empty_like(L)
+    lib = _lib.load()
+    ws = _ws(lib.nsgp_trtri_workspace(n, batch, ref.element_size()), ref.device)
+    _lib.call(f'nsgp_trtri_{_sfx(ref)}', _p(L), n, n, n * n, _p(X), n, n * n, batch, _p(ws), ws.numel(), _stream())
+    return X
+
+
+def chol_bwd_phi_sym(P):
+    ref = _chk(P)
+    P = _c(P)
+    n = P.shape[-1]
+    batch = P.shape[0] if P.dim() == 3 else 1
+    S = torch.empty_like(P)
+    _lib.call(f'nsgp_chol_bwd_phi_sym_{_sfx(ref)}', _p(P), _p(S), n, n, n * n, batch, _stream())
+    return S
+
+
+def cast(t, dtype):
+    """float32 <-> float64 copy on the current stream (row-major, any leading shape)."""
+    _chk(t)
+    if t.dtype == dtype:
+        return t
+    t = _c(t)
+    out = torch.empty(t.shape, dtype=dtype, device=t.device)
+    cols = t.shape[-1] if t.dim() else 1
+    rows = t.numel() // max(cols, 1)
+    name = 'nsgp_cast_f64_to_f32' if dtype == torch.float32 else 'nsgp_cast_f32_to_f64'
+    _lib.call(name, _p(t), cols, _p(out), cols, rows, cols, _stream())
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# K6 / K7 raw ops
+# --------------------------------------------------------------------------------------------
+def svgp_colstats(A, C, m, base):
+    ref = _chk(A, C, m, base)
+    A, C, m, base = _c(A), _c(C), _c(m), _c(base.reshape(-1))
+    batch, M, n = A.shape
+    if C.shape != A.shape or m.shape != (batch, M) or base.shape != (batch,):
+        raise BackendError('svgp_colstats: shapes')
+    mean = torch.empty((batch, n), dtype=ref.dtype, device=ref.device)
+    var = torch.empty_like(mean)
+    _lib.call(f'nsgp_svgp_colstats_{_sfx(ref)}', _p(A), _p(C), _p(m), _p(base), batch, M, n, _p(mean), _p(var),
+              _stream())
+    return mean, var
+
+
+def svgp_colstats_bwd(A, C, m, gmean, gvar):
+    ref = _chk(A, C, m, gmean, gvar)
+    A, C, m, gmean, gvar = _c(A), _c(C), _c(m), _c(gmean), _c(gvar)
+    batch, M, n = A.shape
+    if gmean.shape != (batch, n) or gvar.shape != (batch, n):
+        raise BackendError('svgp_colstats_bwd: shapes')
+    Abar, C2 = torch.empty_like(A), torch.empty_like(C)
+    mbar = torch.empty_like(m)
+    _lib.call(f'nsgp_svgp_colstats_bwd_{_sfx(ref)}', _p(A), _p(C), _p(m), _p(gmean), _p(gvar), batch, M, n,
+              _p(Abar), _p(C2), _p(mbar), _stream())
+    return Abar, C2, mbar
+
+
+def dgp_sample(mean, var, eps):
+    """h[s,i,c] = mean[c,s',i] + sqrt(var[c,s',i]) eps[s,i,c]; mean/var:(b,ns,n) ns in {1,S}; eps:(S,n,b)."""
+    ref = _chk(mean, var, eps)
+    mean, var, eps = _c(mean), _c(var), _c(eps)
+    S, n, b = eps.shape
+    ns = mean.shape[1]
+    if mean.shape != (b, ns, n) or var.shape != mean.shape or ns not in (1, S):
+        raise BackendError('dgp_sample: shapes')
+    h = torch.empty_like(eps)
+    _lib.call(f'nsgp_dgp_sample_fwd_{_sfx(ref)}', _p(mean), _p(var), _p(eps), S, ns, n, b, _p(h), _stream())
+    return h
+
+
+def dgp_sample_bwd(var, eps, gh):
+    ref = _chk(var, eps, gh)
+    var, eps, gh = _c(var), _c(eps), _c(gh)
+    S, n, b = eps.shape
+    ns = var.shape[1]
+    gmean, gvar = torch.empty_like(var), torch.empty_like(var)
+    _lib.call(f'nsgp_dgp_sample_bwd_{_sfx(ref)}', _p(var), _p(eps), _p(gh), S, ns, n, b, _p(gmean), _p(gvar),
+              _stream())
+    return gmean, gvar
+
+
+def _red_ws(ref):
+    return _ws(_lib.load().nsgp_reduce_workspace(0, ref.element_size()), ref.device)
+
+
+def gauss_ell(y, mu, v, noise, scale):
+    ref = _chk(y, mu, v, noise)
+    y, mu, v = _c(y), _c(mu), _c(v)
+    S, n = mu.shape
+    if y.shape != (n,) or v.shape != mu.shape:
+        raise BackendError('gauss_ell: shapes')
+    out = torch.empty(1, dtype=ref.dtype, device=ref.device)
+    ws = _red_ws(ref)
+    _lib.call(f'nsgp_gauss_ell_fwd_{_sfx(ref)}', _p(y), _p(mu), _p(v), _p(noise.reshape(1)), S, n, float(scale),
+              _p(out), _p(ws), ws.numel(), _stream())
+    return out
+
+
+def gauss_ell_bwd(y, mu, v, noise, scale, gout, need_noise=True):
+    ref = _chk(y, mu, v, noise)
+    y, mu, v = _c(y), _c(mu), _c(v)
+    S, n = mu.shape
+    gmu, gv = torch.empty_like(mu), torch.empty_like(mu)
+    gn = torch.empty(1, dtype=ref.dtype, device=ref.device) if need_noise else None
+    ws = _red_ws(ref)
+    _lib.call(f'nsgp_gauss_ell_bwd_{_sfx(ref)}', _p(y), _p(mu), _p(v), _p(noise.reshape(1)), S, n, float(scale),
+              float(gout), _p(gmu), _p(gv), _p(gn), _p(ws), ws.numel(), _stream())
+    return gmu, gv, gn
+
+
+def kl_whitened(m, Lq):
+    ref = _chk(m, Lq)
+    m, Lq = _c(m), _c(Lq)
+    if m.dim() == 1:
+        m, Lq = m.unsqueeze(0), Lq.unsqueeze(0)
+    batch, M = m.shape
+    if Lq.shape != (batch, M, M):
+        raise BackendError('kl_whitened: shapes')
+    out = torch.empty(batch, dtype=ref.dtype, device=ref.device)
+    ws = _red_ws(ref)
+    _lib.call(f'nsgp_kl_whitened_fwd_{_sfx(ref)}', _p(m), _p(Lq), batch, M, _p(out), _p(ws), ws.numel(), _stream())
+    return out
+
+
+def kl_whitened_bwd(m, Lq, gout):
+    ref = _chk(m, Lq)
+    shp_m, shp_L = m.shape, Lq.shape
+    m, Lq = _c(m), _c(Lq)
+    if m.dim() == 1:
+        m, Lq = m.unsqueeze(0), Lq.unsqueeze(0)
+    batch, M = m.shape
+    gm, gL = torch.empty_like(m), torch.empty_like(Lq)
+    _lib.call(f'nsgp_kl_whitened_bwd_{_sfx(ref)}', _p(m), _p(Lq), batch, M, float(gout), _p(gm), _p(gL), _stream())
+    return gm.reshape(shp_m), gL.reshape(shp_L)
+
+
+def philox_normal(seed, stream_id, row0, S, n, b, dtype=torch.float32, device='cuda'):
+    """eps:(S,n,b) standard normals keyed by (seed, stream_id, global row, sample, column)."""
+    eps = torch.empty((S, n, b), dtype=dtype, device=device)
+    if not eps.is_cuda:
+        raise BackendError('philox_normal: CUDA device required')
+    with torch.cuda.device(eps.device):
+        _lib.call(f'nsgp_philox_normal_{_sfx(eps)}', ctypes.c_uint64(seed), ctypes.c_uint64(stream_id), row0, S, n,
+                  b, _p(eps), _stream())
+    return eps
+
+
+def adam_step_(p, g, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    _chk(p, g, exp_avg, exp_avg_sq)
+    if p.dtype != torch.float32 or not all(t.is_contiguous() for t in (p, g, exp_avg, exp_avg_sq)):
+        raise BackendError('adam_step_: contiguous float32 flat buffers expected')
+    _lib.call('nsgp_adam_step_f32', _p(p), _p(g), _p(exp_avg), _p(exp_avg_sq), p.numel(), float(lr), float(beta1),
+              float(beta2), float(eps), int(step), float(grad_scale), _stream())
+    return p
+
+
+# --------------------------------------------------------------------------------------------
+# autograd Functions
+# --------------------------------------------------------------------------------------------
+class GibbsKernelFn(torch.autograd.Function):
+    """K = os * Gibbs(x1,x2;ell1,ell2) + diag_add*I  (GibbsKernel.forward under GibbsSafeScaleKernel,
+    models/gibbs_kernels.py:135-168).  Pass the same tensor as ell1 and ell2 for K_xx: autograd then
+    sums both roles."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, ell1, ell2, outputscale, diag_add):
+        ctx.save_for_backward(x1, x2, ell1, ell2, outputscale)
+        ctx.has_diag = diag_add is not None
+        return gibbs_build(x1, x2, ell1, ell2, outputscale, diag_add)
+
+    @staticmethod
+    def backward(ctx, G):
+        x1, x2, ell1, ell2, outputscale = ctx.saved_tensors
+        need_x = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        g_l1, g_l2, g_x1, g_x2, g_os = gibbs_build_bwd(x1, x2, ell1, ell2, outputscale, G, need_x=need_x)
+        g_diag = None
+        if ctx.has_diag and ctx.needs_input_grad[5]:
+            g_diag = torch.diagonal(G).sum().reshape(())
+        g_osr = None
+        if outputscale is not None and ctx.needs_input_grad[4]:
+            g_osr = g_os.reshape(outputscale.shape)
+        return (g_x1 if ctx.needs_input_grad[0] else None, g_x2 if ctx.needs_input_grad[1] else None,
+                g_l1 if ctx.needs_input_grad[2] else None, g_l2 if ctx.needs_input_grad[3] else None,
+                g_osr, g_diag)
+
+
+class RbfKernelFn(torch.autograd.Function):
+    """K[b] = os[b] RBF-ARD(x1, x2; ls[b]) + diag_add I   (gpytorch ScaleKernel(RBFKernel))."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, ls, os_, diag_add):
+        ctx.save_for_backward(x1, x2, ls, os_)
+        return rbf_build(x1, x2, ls, os_, diag_add)
+
+    @staticmethod
+    def backward(ctx, G):
+        x1, x2, ls, os_ = ctx.saved_tensors
+        n1g, n2g = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g_x1, g_x2, g_ls, g_os = rbf_build_bwd(x1, x2, ls, os_, G, need_x1=n1g, need_x2=n2g)
+        if n1g and x1.dim() == 2:
+            g_x1 = g_x1.sum(0)
+        if n2g and x2.dim() == 2:
+            g_x2 = g_x2.sum(0)
+        return (g_x1 if n1g else None, g_x2 if n2g else None, g_ls.reshape(ls.shape), g_os.reshape(os_.shape), None)
+
+
+class Ps2dKernelFn(torch.autograd.Function):
+    """Paciorek-Schervish kernel for per-point 2x2 matrices (models/multivariate_gibbs_kernel.py:98-150)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, s1, s2, jitter):
+        ctx.save_for_backward(x1, x2, s1, s2)
+        ctx.jitter = jitter
+        return ps2d_build(x1, x2, s1, s2, jitter)
+
+    @staticmethod
+    def backward(ctx, G):
+        x1, x2, s1, s2 = ctx.saved_tensors
+        g1, g2 = ps2d_build_bwd(x1, x2, s1, s2, ctx.jitter, G)
+        return None, None, g1 if ctx.needs_input_grad[2] else None, g2 if ctx.needs_input_grad[3] else None, None
+
+
+def _tri_flags(ta, tb, a_lower, b_lower, out_lower):
+    f = 0
+    if a_lower:
+        f |= GEMM_A_UPPER if ta else GEMM_A_LOWER
+    if b_lower:
+        f |= GEMM_B_UPPER if tb else GEMM_B_LOWER
+    if out_lower:
+        f |= GEMM_C_LOWER
+    return f
+
+
+class MatmulFn(torch.autograd.Function):
+    """C = op(A) op(B) with optional lower-triangular structure of the *stored* A / B / C.
+    Differentiable to any order (backward recurses through `matmul`)."""
+
+    @staticmethod
+    def forward(ctx, A, B, ta, tb, a_lower, b_lower, out_lower):
+        ctx.save_for_backward(A, B)
+        ctx.cfg = (ta, tb, a_lower, b_lower, out_lower)
+        return gemm(A, B, ta, tb, flags=_tri_flags(ta, tb, a_lower, b_lower, out_lower))
+
+    @staticmethod
+    def backward(ctx, G):
+        A, B = ctx.saved_tensors
+        ta, tb, a_lower, b_lower, out_lower = ctx.cfg
+        gA = gB = None
+        if ctx.needs_input_grad[0]:
+            if not ta:
+                gA = matmul(G, B, False, not tb, out_lower, b_lower, a_lower)
+            else:
+                gA = matmul(B, G, tb, True, b_lower, out_lower, a_lower)
+            if A.dim() == 2 and gA.dim() == 3:
+                gA = gA.sum(0)
+        if ctx.needs_input_grad[1]:
+            if not tb:
+                gB = matmul(A, G, not ta, False, a_lower, out_lower, b_lower)
+            else:
+                gB = matmul(G, A, True, ta, out_lower, a_lower, b_lower)
+            if B.dim() == 2 and gB.dim() == 3:
+                gB = gB.sum(0)
+        return gA, gB, None, None, None, None, None
+
+
+def matmul(A, B, ta=False, tb=False, a_lower=False, b_lower=False, out_lower=False):
+    return MatmulFn.apply(A, B, ta, tb, a_lower, b_lower, out_lower)
+
+
+class CholInvFn(torch.autograd.Function):
+    """W = chol(K)^-1 (lower), so that K^-1 = W^T W and log|K| = -2 sum log diag W.
+
+    Replaces psd_safe_cholesky + triangular_solve(eye, .) (models/gibbs_kernels.py:197-208) and the
+    Cholesky factor / inv_matmul of gpytorch's VariationalStrategy and ExactMarginalLogLikelihood.
+    Backward:  Kbar = -W^T sym(Phi(tril(Wbar) W^T)) W  with sym(Phi(B)) = (Phi(B) + Phi(B)^T)/2.
+    """
+
+    @staticmethod
+    def forward(ctx, K):
+        L, info = potrf(K)
+        W = trtri(L)
+        ctx.save_for_backward(W)
+        ctx.mark_non_differentiable(info)
+        return W, info
+
+    @staticmethod
+    def backward(ctx, Wbar, _):
+        (W,) = ctx.saved_tensors
+        Bm = gemm(Wbar, W, False, True, flags=GEMM_A_LOWER | GEMM_B_UPPER)      # tril(Wbar) W^T
+        S = chol_bwd_phi_sym(Bm)                                                 # Phi + Phi^T
+        T = gemm(S, W, False, False, flags=GEMM_B_LOWER)
+        return gemm(W, T, True, False, alpha=-0.5, flags=GEMM_A_UPPER)
+
+
+def chol_inv(K):
+    """Returns (W, info): W lower with K^-1 = W^T W; info int32 per matrix (0 = ok)."""
+    return CholInvFn.apply(K)
+
+
+def gibbs_kernel(x1, x2, ell1, ell2, outputscale=None, diag_add=None):
+    return GibbsKernelFn.apply(x1, x2, ell1, ell2, outputscale, diag_add)
+
+
+def rbf_kernel(x1, x2, ls, os_, diag_add=0.0):
+    """Batched: returns (batch, n1, n2); ls:(batch,D) os:(batch,)."""
+    return RbfKernelFn.apply(x1, x2, ls, os_, diag_add)
+
+
+def ps2d_kernel(x1, x2, s1, s2, jitter=1e-5):
+    return Ps2dKernelFn.apply(x1, x2, s1, s2, jitter)
+
+
+class GaussEllFn(torch.autograd.Function):
+    """scale * sum_{s,i} E_q log N(y_i | f_si, noise)   (GaussianLikelihood.expected_log_prob)."""
+
+    @staticmethod
+    def forward(ctx, y, mu, v, noise, scale):
+        ctx.save_for_backward(y, mu, v, noise)
+        ctx.scale = scale
+        return gauss_ell(y, mu, v, noise, scale).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        y, mu, v, noise = ctx.saved_tensors
+        # g is a 0-dim device tensor; fold it in on the device to avoid a host sync
+        gmu, gv, gn = gauss_ell_bwd(y, mu, v, noise, ctx.scale, 1.0, need_noise=ctx.needs_input_grad[3])
+        return (None, gmu * g, gv * g, (gn * g).reshape(noise.shape) if gn is not None else None, None)
+
+
+class KlWhitenedFn(torch.autograd.Function):
+    """sum_b KL(N(m_b, Lq_b Lq_b^T) || N(0, I))   (whitened VariationalStrategy.kl_divergence)."""
+
+    @staticmethod
+    def forward(ctx, m, Lq):
+        ctx.save_for_backward(m, Lq)
+        return kl_whitened(m, Lq).sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        m, Lq = ctx.saved_tensors
+        gm, gL = kl_whitened_bwd(m, Lq, 1.0)
+        return gm * g, gL * g
+
+
+class DgpSampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mean, var, eps):
+        ctx.save_for_backward(var, eps)
+        return dgp_sample(mean, var, eps)
+
+    @staticmethod
+    def backward(ctx, gh):
+        var, eps = ctx.saved_tensors
+        gm, gv = dgp_sample_bwd(var, eps, gh)
+        return gm, gv, None

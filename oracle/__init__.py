@@ -40,4 +40,4 @@ fetched; the reference ships **no tests, golden vectors or fixtures** for this p
   ``torch.autograd.gradcheck`` for gradients (tests/test_oracle_*.py).
 """
 
-from . import functional, dataprep, kernels, exact, sparse, svgp, psgibbs  # noqa: F401
+from . import functional, dataprep, kernels, exact, sparse, svgp, psgibbs, philox  # noqa: F401
