@@ -1,0 +1,274 @@
+#!/usr/bin/env python3
+"""bench.py -- DSVI ELBO steps/sec of the 2-layer deep GP (BASELINE.json configs[3]) on N MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE B4): DeepGP(num_layers=1) = hidden 3->2 + last 2->1, M=1024 inducing,
+S=10 likelihood samples, minibatch B=4096 of a synthetic N=100,000 spatio-temporal grid
+(100 months x 1,000 cells, time-major, z-scored), float32 with float64 Kzz Cholesky, Adam lr 0.01.
+One step = forward + ELBO + backward + (gradient all-reduce) + Adam update on one minibatch that is
+already resident in HBM.  With N>1 the SAME global minibatch of 4096 rows is sharded over the ranks
+(strong scaling) and the flat gradient bucket is summed with one RCCL all-reduce.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field definitions).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'nonstationary-precip_amd'))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+M_INDUCING, S_SAMPLES, BATCH, N_DATA, SEED = 1024, 10, 4096, 100_000, 173
+MFMA_F32_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+HBM_PEAK_GBS = 8000.0
+
+
+def synthetic_grid(n_months=100, n_cells=1000, seed=SEED):
+    """(t, lon, lat) rows, time-major like data/uib_spatio_temporal.csv; y = sin(2 pi t) g(lon,lat) + noise."""
+    g = torch.Generator().manual_seed(seed)
+    lon = torch.arange(40, dtype=torch.float32) * 0.25 + 72.25
+    lat = torch.arange(25, dtype=torch.float32) * 0.25 + 31.0
+    cells = torch.cartesian_prod(lon, lat)                                  # 1000 cells
+    t = (2000.0 + (torch.arange(n_months, dtype=torch.float32) + 0.5) / 12.0)
+    x = torch.cat([t.repeat_interleave(n_cells).unsqueeze(-1), cells.repeat(n_months, 1)], dim=-1)
+    field = torch.sin(0.8 * (cells[:, 0] - 76.0)) * torch.cos(0.9 * (cells[:, 1] - 34.0)) + 1.5
+    y = torch.sin(2 * math.pi * t).repeat_interleave(n_cells) * field.repeat(n_months) \
+        + 0.1 * torch.randn(n_months * n_cells, generator=g)
+    sx, mx = torch.std_mean(x, dim=-2)
+    sy, my = torch.std_mean(y)
+    return (x - mx) / sx, (y - my) / sy                                    # utils/dataprep.py:35-43
+
+
+class GemmTimer:
+    """HIP-event pairs around every GEMM launch on torch's current stream (the stream the kernels use)."""
+
+    def __init__(self):
+        self.records = []
+
+    def __call__(self, fn, flops):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        self.records.append((e0, e1, flops))
+        return out
+
+    def summary(self):
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b, _ in self.records)
+        return ms, sum(f for _, _, f in self.records), len(self.records)
+
+
+def build(device, dp_world):
+    import models.dgps as dgps
+    from nsgp.gp.mlls import DeepApproximateMLL, VariationalELBO
+    from nsgp.optim import FusedAdam
+    torch.manual_seed(SEED)
+    model = dgps.DeepGP(1, (N_DATA, 3), num_inducing=M_INDUCING).to(device)
+    mll = DeepApproximateMLL(VariationalELBO(model.likelihood, model, N_DATA))
+    opt = FusedAdam(model.parameters(), lr=0.01)
+    return model, mll, opt
+
+
+def cpu_baseline(x, y, idx, seconds_budget=25.0):
+    """The oracle's gpytorch-mirroring op sequence (float32, float64 Cholesky/solve, per-sample Kzz
+    recomputation) for the same model/minibatch on the host cores: forward + backward + Adam."""
+    from oracle import svgp
+    g = torch.Generator().manual_seed(SEED)
+    M, D = M_INDUCING, 3
+    sp = torch.nn.functional.softplus
+
+    def leafs(shapes):
+        return [torch.zeros(s).requires_grad_() for s in shapes]
+    hZ = torch.randn(2, M, D, generator=g).requires_grad_()
+    lZ = torch.randn(M, 2, generator=g).requires_grad_()
+    h_rl, h_ro, l_rl, l_ro, rn, lc = leafs([(2, 1, D), (2,), (1, 2), (), (1,), (1,)])
+    hm = (1e-3 * torch.randn(2, M, generator=g)).requires_grad_()
+    lm = (1e-3 * torch.randn(M, generator=g)).requires_grad_()
+    hL = torch.eye(M).repeat(2, 1, 1).requires_grad_()
+    lL = torch.eye(M).clone().requires_grad_()
+    hw, hb = torch.randn(D, 1, generator=g).requires_grad_(), torch.randn(1, generator=g).requires_grad_()
+    params = [hZ, lZ, h_rl, h_ro, l_rl, l_ro, rn, lc, hm, lm, hL, lL, hw, hb]
+    state, times = {}, []
+    t_all = time.perf_counter()
+    step = 0
+    while True:
+        rows = idx[step % len(idx)]
+        xb, yb = x[rows], y[rows]
+        eps = [torch.randn(S_SAMPLES, BATCH, 2, generator=g)]
+        t0 = time.perf_counter()
+        hidden = dict(Z=hZ, lengthscale=sp(h_rl), outputscale=sp(h_ro), m=hm, Lq=hL, mean=('linear', hw, hb))
+        last = dict(Z=lZ, lengthscale=sp(l_rl), outputscale=sp(l_ro), m=lm, Lq=lL, mean=('constant', lc))
+        loss = -svgp.dsvi_elbo(xb, yb, hidden, last, 1, eps, S_SAMPLES, sp(rn) + 1e-4, N_DATA, mirror=True)
+        grads = torch.autograd.grad(loss, params)
+        with torch.no_grad():
+            new = svgp.adam_step([p.detach() for p in params], list(grads), state)
+            for p, q in zip(params, new):
+                p.copy_(q)
+        times.append(time.perf_counter() - t0)
+        step += 1
+        if step >= 2 and (time.perf_counter() - t_all > seconds_budget or step >= 6):
+            break
+    use = times[1:] if len(times) > 1 else times
+    return len(use) / sum(use), len(times)
+
+
+def gibbs_chol_ms(device):
+    """Second half of the BASELINE metric: Gibbs K build + Cholesky at N=4096, D=2 (B2), fp64 and fp32."""
+    from nsgp import ops
+    out = {}
+    n = 4096
+    g = torch.Generator().manual_seed(SEED)
+    for dt, tag in ((torch.float64, 'f64'), (torch.float32, 'f32')):
+        x = torch.randn(n, 2, generator=g).to(device=device, dtype=dt)
+        e = torch.exp(0.3 * torch.randn(2, n, generator=g) + math.log(0.3)).to(device=device, dtype=dt)
+        os_ = torch.tensor([0.644], dtype=dt, device=device)
+        nz = torch.tensor([0.011], dtype=dt, device=device)
+
+        def timeit(fn, reps=10):
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+        out[f'gibbs_build_ms_{tag}'] = round(timeit(lambda: ops.gibbs_build(x, x, e, e, os_, nz)), 4)
+        K = ops.gibbs_build(x, x, e, e, os_, nz)
+        out[f'potrf_ms_{tag}'] = round(timeit(lambda: ops.potrf(K), reps=5), 4)
+        bytes_ = K.element_size() * (n * n + 2 * 2 * (n + n))
+        out[f'gibbs_build_GBs_{tag}'] = round(bytes_ / (out[f'gibbs_build_ms_{tag}'] * 1e-3) / 1e9, 1)
+        out[f'potrf_TFLOPs_{tag}'] = round(n ** 3 / 3 / (out[f'potrf_ms_{tag}'] * 1e-3) / 1e12, 3)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the nsgp HIP backend has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=device)                  # RCCL on ROCm
+
+    from nsgp import ops
+    from nsgp.dist import DataParallel, PhiloxEps, dp_objective, shard_bounds
+    from nsgp.gp import settings
+
+    x_all, y_all = synthetic_grid()
+    gperm = torch.Generator().manual_seed(SEED)
+    perm = torch.randperm(N_DATA, generator=gperm)
+    n_batches = N_DATA // BATCH
+    idx = [perm[i * BATCH:(i + 1) * BATCH] for i in range(n_batches)]       # shared shuffled index
+    lo, hi = shard_bounds(BATCH, world, rank)
+    xs = [x_all[i[lo:hi]].to(device) for i in idx]                           # resident in HBM
+    ys = [y_all[i[lo:hi]].to(device) for i in idx]
+
+    model, mll, opt = build(device, world)
+    dp = DataParallel(opt.bucket)
+    dp.broadcast_params()
+    eps = PhiloxEps(SEED, row0=lo)
+    model.train()
+
+    def step(k):
+        eps.start_step(k, row0=lo)
+        opt.zero_grad()
+        out = model(xs[k % n_batches])
+        loss = -dp_objective(mll, out, ys[k % n_batches], BATCH, world)
+        loss.backward()
+        dp.allreduce_grads()
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with settings.num_likelihood_samples(S_SAMPLES), settings.eps_provider(eps):
+        for k in range(args.warmup):
+            step(k)
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            loss = step(args.warmup + k)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        final_loss = float(loss.item())
+
+        # roofline of the dominant kernel (gemm_kernel<float,128,128>): re-run the same steps with HIP
+        # events around every GEMM launch (kept out of the timed region above)
+        timer = GemmTimer()
+        ops.set_gemm_timer(timer)
+        nprof = min(args.steps, 5)
+        for k in range(nprof):
+            step(args.warmup + args.steps + k)
+        gemm_ms, gemm_flops, gemm_launches = timer.summary()
+        ops.set_gemm_timer(None)
+
+    result = None
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12
+        result = {
+            'metric': 'dsvi_elbo_steps_per_sec', 'value': round(args.steps / elapsed, 3), 'unit': 'steps/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
+            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': '2-layer DSVI DeepGP (hidden 3->2 + last 2->1), M=1024, S=10, '
+                                   'global minibatch 4096 of synthetic N=1e5 spatio-temporal grid; '
+                                   'fwd+ELBO+bwd+Adam', 'M': M_INDUCING, 'S': S_SAMPLES,
+                       'global_batch': BATCH, 'N': N_DATA, 'parallelism': f'dp{world}',
+                       'kzz_cholesky_dtype': 'f64'},
+            'final_loss': round(final_loss, 5),
+            'roofline': {'bound': 'mfma', 'kernel': 'gemm_kernel<float,128,128> (all GEMM launches of a step)',
+                         'achieved': round(achieved, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
+                         'gemm_ms_per_step': round(gemm_ms / nprof, 3),
+                         'gemm_launches_per_step': gemm_launches // nprof,
+                         'algorithmic_gflop_per_step': round(gemm_flops / nprof / 1e9, 2)},
+        }
+        if world == 1:
+            result.update(gibbs_chol_ms(device))
+            if not args.no_cpu_baseline:
+                torch.set_num_threads(os.cpu_count() or 1)
+                v, nsteps = cpu_baseline(x_all, y_all, idx)
+                result['cpu_baseline'] = {'value': round(v, 4), 'unit': 'steps/s', 'cores': torch.get_num_threads(),
+                                          'kind': 'port',
+                                          'sample': f'{nsteps} full DSVI steps (first discarded) of the same '
+                                                    'M=1024/S=10/B=4096 workload, oracle in gpytorch-mirror mode'}
+                result['speedup_vs_cpu'] = round(result['value'] / v, 1)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

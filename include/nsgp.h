@@ -195,10 +195,11 @@ int nsgp_dgp_sample_bwd_f64(const double* var, const double* eps, const double* 
 
 /* ------------------------------------------------------------------------------------------
  * K7  ELBO reductions.
- *   gauss_ell: out[0] = scale * sum_{s,i} -0.5*(((y_i-mu_si)^2 + v_si)/noise + log noise + log 2pi)
- *              (GaussianLikelihood.expected_log_prob + VariationalELBO/DeepApproximateMLL means,
+ *   gauss_ell: out[s] = scale * sum_i -0.5*(((y_i-mu_si)^2 + v_si)/noise + log noise + log 2pi)
+ *              (GaussianLikelihood.expected_log_prob summed over the minibatch, one value per sample
+ *               s as VariationalELBO returns it; DeepApproximateMLL then averages over s --
  *               experiments/deepgp_spatial_bench.py:61,84-88); noise:(1) device.
- *              bwd writes gmu, gv (S,n) and gnoise (1) for upstream gradient gout (host scalar).
+ *              bwd: upstream gout:(S) on the DEVICE -> gmu, gv (S,n) and gnoise (1).
  *   kl_whitened: out[b] = 0.5*(||Lq_b||_F^2(lower) + m_b.m_b - M - 2 sum log|diag Lq_b|)
  *              (CholeskyVariationalDistribution vs N(0,I)); bwd writes gm, gLq (lower).
  * ------------------------------------------------------------------------------------------ */
@@ -206,12 +207,12 @@ size_t nsgp_reduce_workspace(int64_t n_elems, int elem_size);
 int nsgp_gauss_ell_fwd_f32(const float* y, const float* mu, const float* v, const float* noise,
                            int64_t S, int64_t n, float scale, float* out, void* ws, size_t ws_bytes, void* stream);
 int nsgp_gauss_ell_bwd_f32(const float* y, const float* mu, const float* v, const float* noise,
-                           int64_t S, int64_t n, float scale, float gout, float* gmu, float* gv, float* gnoise,
+                           int64_t S, int64_t n, float scale, const float* gout, float* gmu, float* gv, float* gnoise,
                            void* ws, size_t ws_bytes, void* stream);
 int nsgp_gauss_ell_fwd_f64(const double* y, const double* mu, const double* v, const double* noise,
                            int64_t S, int64_t n, double scale, double* out, void* ws, size_t ws_bytes, void* stream);
 int nsgp_gauss_ell_bwd_f64(const double* y, const double* mu, const double* v, const double* noise,
-                           int64_t S, int64_t n, double scale, double gout, double* gmu, double* gv, double* gnoise,
+                           int64_t S, int64_t n, double scale, const double* gout, double* gmu, double* gv, double* gnoise,
                            void* ws, size_t ws_bytes, void* stream);
 int nsgp_kl_whitened_fwd_f32(const float* m, const float* Lq, int64_t batch, int64_t M, float* out,
                              void* ws, size_t ws_bytes, void* stream);

@@ -98,7 +98,6 @@ __global__ void sample_bwd_kernel(const T* __restrict__ var, const T* __restrict
 }
 
 // ---- generic two-stage sum ---------------------------------------------------------------------
-constexpr int RED_BLOCKS = 512;
 
 template <typename T>
 __global__ __launch_bounds__(256) void reduce_final_kernel(const T* __restrict__ part, int64_t nparts, int64_t nout,
@@ -112,33 +111,37 @@ __global__ __launch_bounds__(256) void reduce_final_kernel(const T* __restrict__
     if (threadIdx.x == 0) out[o] = scale * s + add;
 }
 
-// ---- gaussian expected log-likelihood -----------------------------------------------------------
+// ---- gaussian expected log-likelihood (per sample row s) -------------------------------------------
+// part[s * gridDim.x + blk] = (gout ? gout[s] : 1) * sum over a chunk of row s of
+//     want_gnoise ? 1/2 (e/s2^2 - 1/s2) : -1/2 (e/s2 + log s2 + log 2pi),  e = (y - mu)^2 + v
 template <typename T>
 __global__ __launch_bounds__(256) void gauss_ell_part_kernel(const T* __restrict__ y, const T* __restrict__ mu,
                                                              const T* __restrict__ v, const T* __restrict__ noise,
-                                                             int64_t S, int64_t n, int want_gnoise,
+                                                             const T* __restrict__ gout, int64_t n, int want_gnoise,
                                                              T* __restrict__ part) {
     __shared__ T lds[4];
+    const int64_t s = blockIdx.y;
     const T s2 = noise[0];
     const T is2 = T(1) / s2, ls2 = t_log(s2);
     const T l2pi = T(1.8378770664093454835606594728112);
     T acc = T(0);
-    const int64_t tot = S * n;
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < tot; idx += (int64_t)gridDim.x * 256) {
-        const T d = y[idx % n] - mu[idx];
-        const T e = d * d + v[idx];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const T d = y[i] - mu[s * n + i];
+        const T e = d * d + v[s * n + i];
         acc += want_gnoise ? T(0.5) * (e * is2 * is2 - is2) : T(-0.5) * (e * is2 + ls2 + l2pi);
     }
     acc = block_sum_256(acc, lds);
-    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+    if (threadIdx.x == 0) part[s * gridDim.x + blockIdx.x] = gout ? gout[s] * acc : acc;
 }
 
 template <typename T>
 __global__ void gauss_ell_bwd_kernel(const T* __restrict__ y, const T* __restrict__ mu, const T* __restrict__ noise,
-                                     int64_t S, int64_t n, T coef, T* __restrict__ gmu, T* __restrict__ gv) {
+                                     const T* __restrict__ gout, int64_t S, int64_t n, T scale,
+                                     T* __restrict__ gmu, T* __restrict__ gv) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= S * n) return;
     const T is2 = T(1) / noise[0];
+    const T coef = gout[idx / n] * scale;
     gmu[idx] = coef * (y[idx % n] - mu[idx]) * is2;
     gv[idx] = T(-0.5) * coef * is2;
 }
@@ -228,38 +231,48 @@ int sample_bwd_impl(const T* var, const T* eps, const T* gh, int64_t S, int64_t 
     return nsgp_launch_status();
 }
 
+static inline int64_t gauss_blocks(int64_t n) {
+    int64_t nblk = cdiv64(n, 1024);
+    if (nblk > 64) nblk = 64;
+    if (nblk < 1) nblk = 1;
+    return nblk;
+}
+
 template <typename T>
 int gauss_fwd_impl(const T* y, const T* mu, const T* v, const T* noise, int64_t S, int64_t n, T scale, T* out,
                    void* ws, size_t wsb, void* stream) {
     if (!y) return -1; if (!mu) return -2; if (!v) return -3; if (!noise) return -4;
-    if (S < 0) return -5; if (n < 0) return -6; if (!out) return -8;
-    if (!ws || wsb < RED_BLOCKS * sizeof(T)) return -9;
+    if (S < 0 || S > 65535) return -5; if (n < 0) return -6; if (!out) return -8;
+    if (S == 0) return 0;
+    const int64_t nblk = gauss_blocks(n);
+    if (!ws || wsb < (size_t)(S * nblk) * sizeof(T)) return -9;
     hipStream_t st = (hipStream_t)stream;
-    int64_t nblk = cdiv64(S * n, 256); if (nblk > RED_BLOCKS) nblk = RED_BLOCKS; if (nblk < 1) nblk = 1;
-    hipLaunchKernelGGL((gauss_ell_part_kernel<T>), dim3((unsigned)nblk), dim3(256), 0, st, y, mu, v, noise, S, n, 0,
-                       (T*)ws);
-    hipLaunchKernelGGL((reduce_final_kernel<T>), dim3(1), dim3(256), 0, st, (const T*)ws, nblk, (int64_t)1, scale,
+    hipLaunchKernelGGL((gauss_ell_part_kernel<T>), dim3((unsigned)nblk, (unsigned)S), dim3(256), 0, st, y, mu, v, noise,
+                       (const T*)nullptr, n, 0, (T*)ws);
+    hipLaunchKernelGGL((reduce_final_kernel<T>), dim3((unsigned)S), dim3(256), 0, st, (const T*)ws, nblk, S, scale,
                        T(0), out);
     return nsgp_launch_status();
 }
 
 template <typename T>
-int gauss_bwd_impl(const T* y, const T* mu, const T* v, const T* noise, int64_t S, int64_t n, T scale, T gout, T* gmu,
-                   T* gv, T* gnoise, void* ws, size_t wsb, void* stream) {
+int gauss_bwd_impl(const T* y, const T* mu, const T* v, const T* noise, int64_t S, int64_t n, T scale, const T* gout,
+                   T* gmu, T* gv, T* gnoise, void* ws, size_t wsb, void* stream) {
     if (!y) return -1; if (!mu) return -2; if (!v) return -3; if (!noise) return -4;
-    if (S < 0) return -5; if (n < 0) return -6; if (!gmu) return -9; if (!gv) return -10;
+    if (S < 0 || S > 65535) return -5; if (n < 0) return -6; if (!gout) return -8; if (!gmu) return -9;
+    if (!gv) return -10;
     hipStream_t st = (hipStream_t)stream;
     const int64_t tot = S * n;
     if (tot > 0)
         hipLaunchKernelGGL((gauss_ell_bwd_kernel<T>), dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, st, y, mu, noise,
-                           S, n, gout * scale, gmu, gv);
+                           gout, S, n, scale, gmu, gv);
     if (gnoise) {
-        if (!ws || wsb < RED_BLOCKS * sizeof(T)) return -12;
-        int64_t nblk = cdiv64(tot, 256); if (nblk > RED_BLOCKS) nblk = RED_BLOCKS; if (nblk < 1) nblk = 1;
-        hipLaunchKernelGGL((gauss_ell_part_kernel<T>), dim3((unsigned)nblk), dim3(256), 0, st, y, mu, v, noise, S, n,
-                           1, (T*)ws);
-        hipLaunchKernelGGL((reduce_final_kernel<T>), dim3(1), dim3(256), 0, st, (const T*)ws, nblk, (int64_t)1,
-                           gout * scale, T(0), gnoise);
+        const int64_t nblk = gauss_blocks(n);
+        if (!ws || wsb < (size_t)(S * nblk + 1) * sizeof(T)) return -12;
+        if (S > 0)
+            hipLaunchKernelGGL((gauss_ell_part_kernel<T>), dim3((unsigned)nblk, (unsigned)S), dim3(256), 0, st, y, mu,
+                               v, noise, gout, n, 1, (T*)ws);
+        hipLaunchKernelGGL((reduce_final_kernel<T>), dim3(1), dim3(256), 0, st, (const T*)ws, S * nblk, (int64_t)1,
+                           scale, T(0), gnoise);
     }
     return nsgp_launch_status();
 }
@@ -336,8 +349,8 @@ int nsgp_gauss_ell_fwd_f32(const float* y, const float* mu, const float* v, cons
     return gauss_fwd_impl<float>(y, mu, v, noise, S, n, scale, out, ws, wsb, stream);
 }
 int nsgp_gauss_ell_bwd_f32(const float* y, const float* mu, const float* v, const float* noise, int64_t S, int64_t n,
-                           float scale, float gout, float* gmu, float* gv, float* gnoise, void* ws, size_t wsb,
-                           void* stream) {
+                           float scale, const float* gout, float* gmu, float* gv, float* gnoise, void* ws,
+                           size_t wsb, void* stream) {
     return gauss_bwd_impl<float>(y, mu, v, noise, S, n, scale, gout, gmu, gv, gnoise, ws, wsb, stream);
 }
 int nsgp_gauss_ell_fwd_f64(const double* y, const double* mu, const double* v, const double* noise, int64_t S,
@@ -345,8 +358,8 @@ int nsgp_gauss_ell_fwd_f64(const double* y, const double* mu, const double* v, c
     return gauss_fwd_impl<double>(y, mu, v, noise, S, n, scale, out, ws, wsb, stream);
 }
 int nsgp_gauss_ell_bwd_f64(const double* y, const double* mu, const double* v, const double* noise, int64_t S,
-                           int64_t n, double scale, double gout, double* gmu, double* gv, double* gnoise, void* ws,
-                           size_t wsb, void* stream) {
+                           int64_t n, double scale, const double* gout, double* gmu, double* gv, double* gnoise,
+                           void* ws, size_t wsb, void* stream) {
     return gauss_bwd_impl<double>(y, mu, v, noise, S, n, scale, gout, gmu, gv, gnoise, ws, wsb, stream);
 }
 int nsgp_kl_whitened_fwd_f32(const float* m, const float* Lq, int64_t batch, int64_t M, float* out, void* ws,

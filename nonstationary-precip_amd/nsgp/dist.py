@@ -1,0 +1,67 @@
+"""Data-parallel DSVI over RCCL/xGMI: one process per GPU, parameters replicated, the minibatch
+sharded, ONE sum-all-reduce of the flat gradient bucket per step.
+
+    loss_r = -( (B_r / B) * mean_s[ sum_{i in r} ELL_{s,i} / B_r ] - KL / (G * N_data) )
+    sum_r loss_r == the single-GPU loss   (so the all-reduce is a plain SUM, no rescale)
+
+The reparameterisation noise comes from a counter-based generator keyed by the GLOBAL row index,
+so the union of the ranks' draws equals the single-GPU draw (partition invariance).
+Kzz build + Cholesky are parameter-only work and are replicated, not sharded.
+`backend='nccl'` is RCCL on ROCm; the CPU tests use gloo."""
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+def shard_bounds(n, world, rank):
+    """Contiguous split of n rows over `world` ranks (first n % world ranks get one more)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class PhiloxEps:
+    """settings.eps_provider callable: eps[s, i, c] keyed by (seed, step, call index, global row)."""
+
+    def __init__(self, seed, row0=0):
+        self.seed, self.row0 = int(seed), int(row0)
+        self.step, self.call = 0, 0
+
+    def start_step(self, step, row0=None):
+        self.step, self.call = int(step), 0
+        if row0 is not None:
+            self.row0 = int(row0)
+
+    def __call__(self, shape, dtype, device):
+        S, n, b = shape
+        stream_id = (self.step << 32) | self.call
+        self.call += 1
+        return ops.philox_normal(self.seed, stream_id, self.row0, S, n, b, dtype=dtype, device=device)
+
+
+def dp_objective(mll, output, y_local, batch_global, world):
+    """Rank-local share of DeepApproximateMLL(VariationalELBO(...))(output, y): see module docstring."""
+    base = getattr(mll, 'base_mll', mll)
+    b_local = y_local.shape[-1]
+    ell = base._log_likelihood_term(output, y_local, num_batch=b_local)            # (S,)
+    kl = base.model.variational_strategy.kl_divergence() / (base.num_data / base.beta)
+    return ((b_local / batch_global) * ell - kl / world).mean(0)
+
+
+class DataParallel:
+    """Wraps a FlatBucket: `allreduce_grads()` sums the bucket over the process group."""
+
+    def __init__(self, bucket, group=None):
+        self.bucket, self.group = bucket, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def broadcast_params(self, src=0):
+        if self.world > 1:
+            dist.broadcast(self.bucket.flat_p, src=src, group=self.group)
+
+    def allreduce_grads(self, async_op=False):
+        if self.world > 1:
+            return dist.all_reduce(self.bucket.flat_g, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        return None

@@ -1,0 +1,102 @@
+"""Objectives [gpytorch.mlls recalled, SURVEY A.5]:
+ExactMarginalLogLikelihood = [log N(y | mu, K + noise I) + added-loss terms + sum priors] / N
+VariationalELBO = sum_i E_q log p(y_i | f_i) / B  -  KL / num_data  (+ priors / num_data - added losses)
+DeepApproximateMLL = mean over the likelihood-sample dimension
+InducingPointKernelAddedLossTerm = -1/2 sum_i (k_ii - q_ii) / noise   (Titsias trace term)."""
+import torch
+
+from .. import ops
+from .likelihoods import GaussianLikelihood
+from .module import Module
+
+
+class AddedLossTerm:
+    def loss(self, *params):
+        raise NotImplementedError
+
+
+class InducingPointKernelAddedLossTerm(AddedLossTerm):
+    def __init__(self, prior_dist, variational_dist, likelihood):
+        self.prior_dist, self.variational_dist, self.likelihood = prior_dist, variational_dist, likelihood
+
+    def loss(self, *params):
+        prior_diag = self.prior_dist.lazy_covariance_matrix.diag()
+        var_diag = self.variational_dist.lazy_covariance_matrix.diag()
+        diag = var_diag - prior_diag
+        noise_diag = self.likelihood._shaped_noise_covar(prior_diag.shape, *params).diag()
+        return 0.5 * (diag / noise_diag).sum()
+
+
+class MarginalLogLikelihood(Module):
+    def __init__(self, likelihood, model):
+        super().__init__()
+        self.likelihood = likelihood
+        self.model = model
+
+
+class ExactMarginalLogLikelihood(MarginalLogLikelihood):
+    def _add_other_terms(self, res, params):
+        for term in self.model.added_loss_terms():
+            res = res + term.loss(*params)
+        for _, module, prior, closure, _ in self.named_priors():
+            res = res + prior.log_prob(closure(module)).sum()
+        return res
+
+    def forward(self, function_dist, target, *params):
+        output = self.likelihood(function_dist, *params)
+        res = output.log_prob(target)
+        res = self._add_other_terms(res, params)
+        num_data = function_dist.event_shape.numel()
+        return res / num_data
+
+
+class _ApproximateMarginalLogLikelihood(MarginalLogLikelihood):
+    def __init__(self, likelihood, model, num_data, beta=1.0, combine_terms=True):
+        super().__init__(likelihood, model)
+        self.combine_terms = combine_terms
+        self.num_data = num_data
+        self.beta = beta
+
+    def _log_likelihood_term(self, approximate_dist_f, target, **kwargs):
+        raise NotImplementedError
+
+    def forward(self, approximate_dist_f, target, **kwargs):
+        num_batch = approximate_dist_f.event_shape[0]
+        log_likelihood = self._log_likelihood_term(approximate_dist_f, target, num_batch=num_batch, **kwargs)
+        kl_divergence = self.model.variational_strategy.kl_divergence() / (self.num_data / self.beta)
+        added_loss = torch.zeros_like(log_likelihood)
+        had_added = False
+        for term in self.model.added_loss_terms():
+            added_loss = added_loss + term.loss()
+            had_added = True
+        log_prior = torch.zeros_like(log_likelihood)
+        for _, module, prior, closure, _ in self.named_priors():
+            log_prior = log_prior + prior.log_prob(closure(module)).sum() / self.num_data
+        if self.combine_terms:
+            return log_likelihood - kl_divergence + log_prior - added_loss
+        if had_added:
+            return log_likelihood, kl_divergence, log_prior, added_loss
+        return log_likelihood, kl_divergence, log_prior
+
+
+class VariationalELBO(_ApproximateMarginalLogLikelihood):
+    def _log_likelihood_term(self, variational_dist_f, target, num_batch=None, **kwargs):
+        """likelihood.expected_log_prob(target, q(f)).sum(-1) / B; one fused reduction kernel for the
+        Gaussian likelihood with a (S, B) diagonal q(f) (the DSVI hot path)."""
+        mean, var = variational_dist_f.mean, variational_dist_f.variance
+        B = num_batch if num_batch is not None else mean.shape[-1]
+        if isinstance(self.likelihood, GaussianLikelihood) and mean.is_cuda and target.dim() == 1:
+            shp = mean.shape[:-1]
+            out = ops.GaussEllFn.apply(target, mean.reshape(-1, mean.shape[-1]), var.reshape(-1, mean.shape[-1]),
+                                       self.likelihood.noise, 1.0 / B)
+            return out.reshape(shp)
+        return self.likelihood.expected_log_prob(target, variational_dist_f, **kwargs).sum(-1) / B
+
+
+class DeepApproximateMLL(MarginalLogLikelihood):
+    def __init__(self, base_mll):
+        super().__init__(base_mll.likelihood, base_mll.model)
+        self.base_mll = base_mll
+
+    def forward(self, approximate_dist_f, target, **kwargs):
+        return self.base_mll(approximate_dist_f, target, **kwargs).mean(0)

@@ -1,0 +1,120 @@
+"""Module base with constraints, priors and added-loss terms -- the gpytorch.Module mechanics the
+reference models rely on (register_parameter / register_prior with a closure at
+models/nonstationary_models.py:31-38, update_added_loss_term at models/gibbs_kernels.py:261,
+`model.covar_module.outputscale = 0.644` style setters at experiments/spatial_exp.py:176-186)
+[gpytorch semantics recalled, SURVEY A.1/A.5]."""
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from .constraints import Interval
+
+
+class Module(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self._added_loss_terms = OrderedDict()
+        self._priors = OrderedDict()
+        self._constraints = OrderedDict()
+
+    # ---- parameters / constraints ---------------------------------------------------------
+    def register_parameter(self, name, parameter):
+        if '_parameters' not in self.__dict__:
+            raise AttributeError('Cannot assign parameter before Module.__init__() call')
+        super().register_parameter(name, parameter)
+
+    def register_constraint(self, param_name, constraint, replace=True):
+        if param_name not in self._parameters:
+            raise RuntimeError(f'Attempting to register constraint for nonexistent parameter {param_name}')
+        name = param_name + '_constraint'
+        self.add_module(name, constraint)
+        self._constraints[name] = constraint
+
+    def constraint_for_parameter_name(self, param_name):
+        return self._constraints.get(param_name + '_constraint')
+
+    def initialize(self, **kwargs):
+        """Set parameters (raw names) or constrained properties by keyword, e.g. initialize(noise=0.011)."""
+        for name, val in kwargs.items():
+            if isinstance(val, (int, float)):
+                val = float(val)
+            if '.' in name:
+                mod, rest = name.split('.', 1)
+                getattr(self, mod).initialize(**{rest: val})
+            elif name in self._parameters:
+                p = self._parameters[name]
+                with torch.no_grad():
+                    if torch.is_tensor(val):
+                        p.copy_(val.to(p).expand_as(p) if val.numel() != p.numel() else val.to(p).view_as(p))
+                    else:
+                        p.fill_(val)
+            elif hasattr(type(self), name) and isinstance(getattr(type(self), name), property):
+                setattr(self, name, val)
+            else:
+                raise AttributeError(f'Unknown parameter {name} for {type(self).__name__}')
+        return self
+
+    def _set_constrained(self, raw_name, value):
+        """Apply the inverse transform and write the raw parameter in place (keeps Parameter identity)."""
+        p = self._parameters[raw_name]
+        if not torch.is_tensor(value):
+            value = torch.as_tensor(value)
+        value = value.to(dtype=p.dtype, device=p.device)
+        c = self.constraint_for_parameter_name(raw_name)
+        raw = c.inverse_transform(value) if c is not None else value
+        with torch.no_grad():
+            p.copy_(raw.expand_as(p) if raw.numel() != p.numel() else raw.reshape(p.shape))
+
+    def _get_constrained(self, raw_name):
+        p = self._parameters[raw_name]
+        c = self.constraint_for_parameter_name(raw_name)
+        return c.transform(p) if c is not None else p
+
+    # ---- priors -----------------------------------------------------------------------------
+    def register_prior(self, name, prior, param_or_closure, setting_closure=None):
+        if isinstance(param_or_closure, str):
+            pname = param_or_closure
+            if pname not in self._parameters and not hasattr(self, pname):
+                raise AttributeError(f'Unknown parameter {pname} for {type(self).__name__}')
+
+            def closure(module, _p=pname):
+                return getattr(module, _p)
+        else:
+            closure = param_or_closure
+        self.add_module(name, prior)
+        self._priors[name] = (prior, closure, setting_closure)
+
+    def named_priors(self, memo=None, prefix=''):
+        if memo is None:
+            memo = set()
+        if hasattr(self, '_priors'):
+            for name, (prior, closure, inv) in self._priors.items():
+                if prior is not None and prior not in memo:
+                    memo.add(prior)
+                    yield prefix + ('.' if prefix else '') + name, self, prior, closure, inv
+        for mname, module in self.named_children():
+            sub = prefix + ('.' if prefix else '') + mname
+            if hasattr(module, 'named_priors'):
+                yield from module.named_priors(memo, sub)
+
+    # ---- added loss terms -------------------------------------------------------------------
+    def register_added_loss_term(self, name):
+        self._added_loss_terms[name] = None
+
+    def update_added_loss_term(self, name, added_loss_term):
+        self._added_loss_terms[name] = added_loss_term
+
+    def added_loss_terms(self):
+        seen = set()
+        for m in self.modules():
+            if id(m) in seen:
+                continue
+            seen.add(id(m))
+            for term in getattr(m, '_added_loss_terms', {}).values():
+                if term is not None:
+                    yield term
+
+    def hyperparameters(self):
+        for _, p in self.named_parameters():
+            yield p

@@ -1,0 +1,109 @@
+"""Context-manager settings, restating the gpytorch.settings the in-scope scripts touch [SURVEY A.7]:
+num_likelihood_samples (experiments/deepgp_spatial_bench.py:84), max_cg_iterations
+(experiments/spatial_exp.py:199), cholesky_jitter (called as a bare no-op statement),
+sgpr_diagonal_correction (models/gibbs_kernels.py:228), max_cholesky_size, debug.
+Plus two knobs of this build: variational_cholesky_jitter (default 1e-4) and the
+reparameterisation-noise provider used for partition-invariant data-parallel sampling."""
+import torch
+
+
+class _value_context:
+    _global_value = None
+
+    @classmethod
+    def value(cls, *a):
+        return cls._global_value
+
+    @classmethod
+    def _set_value(cls, v):
+        cls._global_value = v
+
+    def __init__(self, value):
+        self._orig = self.__class__.value()
+        self._new = value
+
+    def __enter__(self):
+        self.__class__._set_value(self._new)
+        return self
+
+    def __exit__(self, *exc):
+        self.__class__._set_value(self._orig)
+        return False
+
+
+class _feature_flag:
+    _state = False
+
+    @classmethod
+    def on(cls):
+        return cls._state
+
+    @classmethod
+    def off(cls):
+        return not cls._state
+
+    @classmethod
+    def _set_state(cls, s):
+        cls._state = s
+
+    def __init__(self, state=True):
+        self.prev = self.__class__.on()
+        self.state = state
+
+    def __enter__(self):
+        self.__class__._set_state(self.state)
+        return self
+
+    def __exit__(self, *exc):
+        self.__class__._set_state(self.prev)
+        return False
+
+
+class num_likelihood_samples(_value_context):
+    _global_value = 10
+
+
+class max_cg_iterations(_value_context):
+    """Accepted for source compatibility; this build always factors with the GPU Cholesky."""
+    _global_value = 1000
+
+
+class max_cholesky_size(_value_context):
+    _global_value = 800
+
+
+class cholesky_jitter(_value_context):
+    _global_value = None
+
+    @classmethod
+    def value(cls, dtype=None):
+        if cls._global_value is not None:
+            return cls._global_value
+        return 1e-8 if dtype == torch.float64 else 1e-6
+
+
+class variational_cholesky_jitter(_value_context):
+    """Jitter added to Kzz in VariationalStrategy (1e-3 in gpytorch < 1.6, settings value afterwards)."""
+    _global_value = 1e-4
+
+    @classmethod
+    def value(cls, dtype=None):
+        return cls._global_value
+
+
+class sgpr_diagonal_correction(_feature_flag):
+    _state = True
+
+
+class debug(_feature_flag):
+    _state = True
+
+
+class fast_pred_var(_feature_flag):
+    _state = False
+
+
+class eps_provider(_value_context):
+    """None -> torch.randn on the input's device (what Normal.rsample does in the reference);
+    otherwise a callable (shape, dtype, device, call_index) -> eps, e.g. nsgp.dist.PhiloxEps."""
+    _global_value = None

@@ -1,0 +1,49 @@
+"""gpytorch.utils.cholesky.psd_safe_cholesky on the MI355X potrf (models/gibbs_kernels.py:201,298).
+
+Semantics [SURVEY A.6]: factor; on failure retry with jitter 1e-6 * 10^i (float32) / 1e-8 * 10^i
+(float64), i < 3, warning each time; raise if still not positive definite."""
+import warnings
+
+import torch
+
+from ... import ops
+from .. import settings
+
+
+class NumericalWarning(RuntimeWarning):
+    pass
+
+
+class NanError(RuntimeError):
+    pass
+
+
+class NotPSDError(RuntimeError):
+    pass
+
+
+def psd_safe_cholesky(A, upper=False, out=None, jitter=None, max_tries=3):
+    L, info = ops.potrf(A)
+    if int(info.max().item()) != 0:                     # the reference syncs here too (torch raises)
+        if torch.isnan(A).any():
+            raise NanError(f'cholesky_cpu: {int(torch.isnan(A).sum())} of {A.numel()} elements are NaN')
+        base = jitter if jitter is not None else settings.cholesky_jitter.value(A.dtype)
+        n = A.shape[-1]
+        eye = torch.eye(n, dtype=A.dtype, device=A.device)
+        ok = False
+        prev = 0.0
+        Ap = A.clone()
+        for i in range(max_tries):
+            jit = base * (10 ** i)
+            Ap = Ap + (jit - prev) * eye
+            prev = jit
+            L, info = ops.potrf(Ap)
+            if int(info.max().item()) == 0:
+                warnings.warn(f'A not p.d., added jitter of {jit:.1e} to the diagonal', NumericalWarning)
+                ok = True
+                break
+        if not ok:
+            raise NotPSDError(f'Matrix not positive definite after repeatedly adding jitter up to {jit:.1e}.')
+    if upper:
+        L = L.transpose(-1, -2)
+    return L

@@ -223,6 +223,16 @@ def _mat_view(t, trans):
     return t, r, c, sr, sc, nb, sb
 
 
+_gemm_timer = None
+
+
+def set_gemm_timer(timer):
+    """bench.py hook: `timer(fn, flops)` must call fn() (the launch) and may bracket it with HIP events.
+    flops = algorithmic 2*M*N*K per batch element, halved for a triangular operand / lower-only output."""
+    global _gemm_timer
+    _gemm_timer = timer
+
+
 def gemm(A, B, ta=False, tb=False, alpha=1.0, beta=0.0, out=None, flags=0):
     """out = alpha * op(A) @ op(B) + beta * out on the matrix cores.  2-D or batched 3-D operands
     (a 2-D operand broadcasts against a 3-D one)."""
@@ -250,9 +260,15 @@ def gemm(A, B, ta=False, tb=False, alpha=1.0, beta=0.0, out=None, flags=0):
     lib = _lib.load()
     wsb = 0 if (flags & GEMM_NO_SPLITK) else lib.nsgp_gemm_workspace(M, N, K, nb, 1, ref.element_size())
     ws = _ws(wsb, ref.device) if wsb else None
-    _lib.call(f'nsgp_gemm_{_sfx(ref)}', M, N, K, float(alpha), _p(A), sam, sak, sba, 0, _p(B), sbk, sbn, sbb, 0,
-              float(beta), _p(out), N, M * N, 0, nb, 1, int(flags), _p(ws), ws.numel() if ws is not None else 0,
-              _stream())
+    def launch():
+        _lib.call(f'nsgp_gemm_{_sfx(ref)}', M, N, K, float(alpha), _p(A), sam, sak, sba, 0, _p(B), sbk, sbn, sbb, 0,
+                  float(beta), _p(out), N, M * N, 0, nb, 1, int(flags), _p(ws), ws.numel() if ws is not None else 0,
+                  _stream())
+    if _gemm_timer is not None:
+        tri = flags & (GEMM_A_LOWER | GEMM_A_UPPER | GEMM_B_LOWER | GEMM_B_UPPER | GEMM_C_LOWER)
+        _gemm_timer(launch, 2.0 * M * N * K * nb * (0.5 if tri else 1.0))
+    else:
+        launch()
     return out
 
 
@@ -377,12 +393,13 @@ def _red_ws(ref):
 
 
 def gauss_ell(y, mu, v, noise, scale):
+    """out[s] = scale * sum_i E_q log N(y_i | f_si, noise);  mu, v:(S,n)  y:(n,)  noise: 1-element tensor."""
     ref = _chk(y, mu, v, noise)
     y, mu, v = _c(y), _c(mu), _c(v)
     S, n = mu.shape
     if y.shape != (n,) or v.shape != mu.shape:
         raise BackendError('gauss_ell: shapes')
-    out = torch.empty(1, dtype=ref.dtype, device=ref.device)
+    out = torch.empty(S, dtype=ref.dtype, device=ref.device)
     ws = _red_ws(ref)
     _lib.call(f'nsgp_gauss_ell_fwd_{_sfx(ref)}', _p(y), _p(mu), _p(v), _p(noise.reshape(1)), S, n, float(scale),
               _p(out), _p(ws), ws.numel(), _stream())
@@ -390,14 +407,16 @@ def gauss_ell(y, mu, v, noise, scale):
 
 
 def gauss_ell_bwd(y, mu, v, noise, scale, gout, need_noise=True):
-    ref = _chk(y, mu, v, noise)
-    y, mu, v = _c(y), _c(mu), _c(v)
+    ref = _chk(y, mu, v, noise, gout)
+    y, mu, v, gout = _c(y), _c(mu), _c(v), _c(gout)
     S, n = mu.shape
+    if gout.shape != (S,):
+        raise BackendError('gauss_ell_bwd: gout must be (S,)')
     gmu, gv = torch.empty_like(mu), torch.empty_like(mu)
     gn = torch.empty(1, dtype=ref.dtype, device=ref.device) if need_noise else None
     ws = _red_ws(ref)
     _lib.call(f'nsgp_gauss_ell_bwd_{_sfx(ref)}', _p(y), _p(mu), _p(v), _p(noise.reshape(1)), S, n, float(scale),
-              float(gout), _p(gmu), _p(gv), _p(gn), _p(ws), ws.numel(), _stream())
+              _p(gout), _p(gmu), _p(gv), _p(gn), _p(ws), ws.numel(), _stream())
     return gmu, gv, gn
 
 
@@ -604,20 +623,20 @@ def ps2d_kernel(x1, x2, s1, s2, jitter=1e-5):
 
 
 class GaussEllFn(torch.autograd.Function):
-    """scale * sum_{s,i} E_q log N(y_i | f_si, noise)   (GaussianLikelihood.expected_log_prob)."""
+    """(S,) vector: scale * sum_i E_q log N(y_i | f_si, noise)   (GaussianLikelihood.expected_log_prob
+    summed over the minibatch, per likelihood sample)."""
 
     @staticmethod
     def forward(ctx, y, mu, v, noise, scale):
         ctx.save_for_backward(y, mu, v, noise)
         ctx.scale = scale
-        return gauss_ell(y, mu, v, noise, scale).reshape(())
+        return gauss_ell(y, mu, v, noise, scale)
 
     @staticmethod
     def backward(ctx, g):
         y, mu, v, noise = ctx.saved_tensors
-        # g is a 0-dim device tensor; fold it in on the device to avoid a host sync
-        gmu, gv, gn = gauss_ell_bwd(y, mu, v, noise, ctx.scale, 1.0, need_noise=ctx.needs_input_grad[3])
-        return (None, gmu * g, gv * g, (gn * g).reshape(noise.shape) if gn is not None else None, None)
+        gmu, gv, gn = gauss_ell_bwd(y, mu, v, noise, ctx.scale, g, need_noise=ctx.needs_input_grad[3])
+        return None, gmu, gv, gn.reshape(noise.shape) if gn is not None else None, None
 
 
 class KlWhitenedFn(torch.autograd.Function):

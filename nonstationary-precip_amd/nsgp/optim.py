@@ -1,0 +1,69 @@
+"""Flat parameter / gradient buckets and a fused Adam step.
+
+The reference optimises with torch.optim.Adam(model.parameters(), lr=0.01)
+(experiments/deepgp_spatial_bench.py:74-76).  Here all trainable parameters live in ONE contiguous
+float32 buffer (parameters and their .grad are views into it), so that
+  * the Adam update is one HIP kernel launch (nsgp_adam_step_f32), and
+  * the data-parallel gradient exchange is one RCCL all-reduce of one bucket (nsgp.dist).
+torch.optim.Adam keeps working on the same model (the views are ordinary Parameters)."""
+import torch
+
+from . import ops
+
+
+class FlatBucket:
+    """Re-homes `params` into one flat buffer; p.data and p.grad become views (device-agnostic)."""
+
+    def __init__(self, params):
+        seen, plist = set(), []
+        for p in params:
+            if p.requires_grad and id(p) not in seen:
+                seen.add(id(p))
+                plist.append(p)
+        if not plist:
+            raise ValueError('FlatBucket: no trainable parameters')
+        dev, dt = plist[0].device, plist[0].dtype
+        for p in plist:
+            if p.device != dev or p.dtype != dt:
+                raise ValueError('FlatBucket: all parameters must share device and dtype')
+        self.params = plist
+        self.numel = sum(p.numel() for p in plist)
+        self.flat_p = torch.empty(self.numel, dtype=dt, device=dev)
+        self.flat_g = torch.zeros(self.numel, dtype=dt, device=dev)
+        off = 0
+        self.offsets = []
+        with torch.no_grad():
+            for p in plist:
+                n = p.numel()
+                self.flat_p[off:off + n].copy_(p.reshape(-1))
+                p.data = self.flat_p[off:off + n].view(p.shape)
+                p.grad = self.flat_g[off:off + n].view(p.shape)
+                self.offsets.append((off, n))
+                off += n
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+        for p, (off, n) in zip(self.params, self.offsets):       # re-attach if something replaced .grad
+            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + off * self.flat_g.element_size():
+                p.grad = self.flat_g[off:off + n].view(p.shape)
+
+
+class FusedAdam:
+    """torch.optim.Adam semantics (no weight decay, no amsgrad) over a FlatBucket, one kernel per step."""
+
+    def __init__(self, params, lr=0.01, betas=(0.9, 0.999), eps=1e-8):
+        self.bucket = params if isinstance(params, FlatBucket) else FlatBucket(list(params))
+        if self.bucket.flat_p.dtype != torch.float32:
+            raise ValueError('FusedAdam: float32 parameters expected')
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.exp_avg = torch.zeros_like(self.bucket.flat_p)
+        self.exp_avg_sq = torch.zeros_like(self.bucket.flat_p)
+        self.steps = 0
+
+    def zero_grad(self, set_to_none=False):
+        self.bucket.zero_grad()
+
+    def step(self, grad_scale=1.0):
+        self.steps += 1
+        ops.adam_step_(self.bucket.flat_p, self.bucket.flat_g, self.exp_avg, self.exp_avg_sq, self.lr,
+                       self.betas[0], self.betas[1], self.eps, self.steps, grad_scale)

@@ -1,0 +1,189 @@
+"""GPU parity of the DSVI deep GP behind models.dgps (the reference's class surface) against the CPU
+oracle: ELBO value, every parameter gradient (through the softplus constraints), predict() outputs.
+The float32 model is compared with the float64 oracle; tolerances are stated at each assert."""
+import math
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+F64 = torch.float64
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+
+
+class _FixedEps:
+    """eps provider returning pre-drawn tensors (the same ones the oracle gets)."""
+
+    def __init__(self, eps_list):
+        self.eps, self.k = eps_list, 0
+
+    def __call__(self, shape, dtype, device):
+        e = self.eps[self.k % len(self.eps)]
+        self.k += 1
+        assert tuple(e.shape) == tuple(shape)
+        return e.to(device=device, dtype=dtype)
+
+
+def _oracle_layers(model):
+    """Clone the model's raw parameters to float64 CPU leaves and build the oracle's layer dicts."""
+    sp = torch.nn.functional.softplus
+    leaves = {}
+
+    def leaf(name, t):
+        leaves[name] = t.detach().cpu().double().clone().requires_grad_()
+        return leaves[name]
+
+    def layer(prefix, mod, linear):
+        vs = mod.variational_strategy
+        p = dict(Z=leaf(prefix + 'Z', vs.inducing_points),
+                 lengthscale=sp(leaf(prefix + 'raw_ls', mod.covar_module.base_kernel.raw_lengthscale)),
+                 outputscale=sp(leaf(prefix + 'raw_os', mod.covar_module.raw_outputscale)),
+                 m=leaf(prefix + 'm', vs._variational_distribution.variational_mean),
+                 Lq=leaf(prefix + 'Lq', vs._variational_distribution.chol_variational_covar))
+        if linear:
+            p['mean'] = ('linear', leaf(prefix + 'w', mod.mean_module.weights), leaf(prefix + 'b', mod.mean_module.bias))
+        else:
+            p['mean'] = ('constant', leaf(prefix + 'c', mod.mean_module.constant))
+        return p
+    hidden = layer('h.', model.layers[0], True)
+    last = layer('l.', model.last_layer, False)
+    noise = sp(leaf('raw_noise', model.likelihood.noise_covar.raw_noise)) + 1e-4
+    return hidden, last, noise, leaves
+
+
+def _model_params(model):
+    h, l_ = model.layers[0], model.last_layer
+    return {
+        'h.Z': h.variational_strategy.inducing_points,
+        'h.raw_ls': h.covar_module.base_kernel.raw_lengthscale, 'h.raw_os': h.covar_module.raw_outputscale,
+        'h.m': h.variational_strategy._variational_distribution.variational_mean,
+        'h.Lq': h.variational_strategy._variational_distribution.chol_variational_covar,
+        'h.w': h.mean_module.weights, 'h.b': h.mean_module.bias,
+        'l.Z': l_.variational_strategy.inducing_points,
+        'l.raw_ls': l_.covar_module.base_kernel.raw_lengthscale, 'l.raw_os': l_.covar_module.raw_outputscale,
+        'l.m': l_.variational_strategy._variational_distribution.variational_mean,
+        'l.Lq': l_.variational_strategy._variational_distribution.chol_variational_covar,
+        'l.c': l_.mean_module.constant, 'raw_noise': model.likelihood.noise_covar.raw_noise,
+    }
+
+
+def _build(num_layers, D, M, seed):
+    import models.dgps as m
+    from nsgp.gp import settings
+    torch.manual_seed(seed)
+    model = m.DeepGP(num_layers, (1000, D), num_inducing=M).cuda()
+    # move away from the trivial initialisation so that every gradient path is exercised
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for mod in (model.layers[0], model.last_layer):
+            vd = mod.variational_strategy._variational_distribution
+            vd.variational_mean.copy_(0.3 * torch.randn(vd.variational_mean.shape, generator=g))
+            Lq = torch.tril(0.1 * torch.randn(vd.chol_variational_covar.shape, generator=g)) + torch.eye(M)
+            vd.chol_variational_covar.copy_(Lq)
+            mod.variational_strategy.variational_params_initialized.fill_(1)
+            mod.covar_module.base_kernel.raw_lengthscale.add_(0.3 * torch.randn(
+                mod.covar_module.base_kernel.raw_lengthscale.shape, generator=g).cuda())
+    return model, settings
+
+
+@pytest.mark.parametrize('num_layers,D,M,B,S', [(1, 3, 40, 315, 3), (2, 2, 64, 128, 4), (1, 2, 130, 200, 10)])
+def test_dsvi_elbo_and_gradients_match_oracle(num_layers, D, M, B, S):
+    _need_gpu()
+    from oracle import svgp
+    from nsgp.gp.mlls import DeepApproximateMLL, VariationalELBO
+    model, settings = _build(num_layers, D, M, 100 + M)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, D, generator=g)
+    y = torch.randn(B, generator=g)
+    eps = [torch.randn(S, B, 2, generator=g) for _ in range(num_layers)]
+    N = 5000
+    mll = DeepApproximateMLL(VariationalELBO(model.likelihood, model, N))
+    model.train()
+    with settings.num_likelihood_samples(S), settings.eps_provider(_FixedEps(eps)):
+        out = model(x.cuda())
+        elbo = mll(out, y.cuda())
+    assert out.mean.shape == (S, B) and out.variance.shape == (S, B)
+    elbo.backward()
+
+    hidden, last, noise, leaves = _oracle_layers(model)
+    ref = svgp.dsvi_elbo(x.double(), y.double(), hidden, last, num_layers, [e.double() for e in eps], S, noise, N)
+    ref.backward()
+    # float32 pipeline vs float64 oracle: ELBO to 2e-4 relative
+    assert abs(float(elbo) - float(ref)) < 2e-4 * abs(float(ref)) + 1e-5
+    for name, p in _model_params(model).items():
+        got, want = p.grad.detach().cpu().double(), leaves[name].grad
+        if name.endswith('Lq'):
+            want = torch.tril(want)
+        scale = float(want.abs().max()) + 1e-12
+        err = float((got - want).abs().max()) / scale
+        assert err < 2e-2, (name, err)                       # per-parameter max-norm relative error
+
+
+def test_predict_matches_oracle_and_full_covariance_is_consistent():
+    _need_gpu()
+    from oracle import svgp
+    model, settings = _build(1, 2, 48, 321)
+    g = torch.Generator().manual_seed(9)
+    n, S = 78, 4
+    x = torch.randn(n, 2, generator=g)
+    y = torch.randn(n, generator=g)
+    eps = [torch.randn(S, n, 2, generator=g)]
+    model.eval()
+    loader = [(x.cuda(), y.cuda())]
+    with settings.num_likelihood_samples(S), settings.eps_provider(_FixedEps(eps)):
+        preds, mus, variances, lls = model.predict(loader)
+        cov = preds.covariance_matrix
+        lp = preds.log_prob(y.cuda())
+    hidden, last, noise, _ = _oracle_layers(model)
+    with torch.no_grad():
+        m_ref, v_ref, ll_ref = svgp.dgp_predict(x.double(), y.double(), hidden, last, 1, [e.double() for e in eps], S,
+                                                noise)
+        mean_f, cov_f = svgp.dgp_forward(x.double(), hidden, last, 1, [e.double() for e in eps], S,
+                                         full_cov_last=True)
+    tol = dict(rtol=2e-3, atol=2e-4)
+    assert torch.allclose(mus.cpu().double(), m_ref, **tol)
+    assert torch.allclose(variances.cpu().double(), v_ref, **tol)
+    assert torch.allclose(lls.cpu().double(), ll_ref, rtol=5e-3, atol=5e-3)
+    cov_ref = cov_f + float(noise) * torch.eye(n, dtype=F64)
+    assert torch.allclose(cov.cpu().double(), cov_ref, rtol=5e-3, atol=5e-4)
+    assert torch.allclose(torch.diagonal(cov, dim1=-1, dim2=-2).cpu().double(), v_ref, **tol)
+    lp_ref = torch.distributions.MultivariateNormal(m_ref, covariance_matrix=cov_ref).log_prob(y.double())
+    assert torch.allclose(lp.cpu().double(), lp_ref, rtol=5e-3, atol=5e-2)
+
+
+def test_fused_adam_and_flat_bucket_train_the_dgp_like_torch_adam():
+    _need_gpu()
+    import copy
+    from nsgp.gp.mlls import DeepApproximateMLL, VariationalELBO
+    from nsgp.optim import FusedAdam
+    model_a, settings = _build(1, 3, 32, 555)
+    model_b = copy.deepcopy(model_a)
+    g = torch.Generator().manual_seed(11)
+    B, S = 256, 3
+    x, y = torch.randn(B, 3, generator=g).cuda(), torch.randn(B, generator=g).cuda()
+    eps = [torch.randn(S, B, 2, generator=g)]
+    opt_a = FusedAdam(model_a.parameters(), lr=0.01)
+    opt_b = torch.optim.Adam(model_b.parameters(), lr=0.01)
+    losses = []
+    for model, opt in ((model_a, opt_a), (model_b, opt_b)):
+        mll = DeepApproximateMLL(VariationalELBO(model.likelihood, model, 1000))
+        model.train()
+        ls = []
+        for it in range(5):
+            with settings.num_likelihood_samples(S), settings.eps_provider(_FixedEps(eps)):
+                opt.zero_grad()
+                loss = -mll(model(x), y)
+                loss.backward()
+                opt.step()
+            ls.append(float(loss))
+        losses.append(ls)
+    assert losses[0][-1] < losses[0][0]                       # it trains
+    for a, b in zip(*losses):
+        assert abs(a - b) < 1e-3 * abs(b) + 1e-4              # fused flat Adam == torch.optim.Adam
+    for pa, pb in zip(model_a.parameters(), model_b.parameters()):
+        assert torch.allclose(pa, pb, rtol=1e-3, atol=1e-4)

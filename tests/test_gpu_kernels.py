@@ -382,17 +382,19 @@ def test_gauss_ell_and_kl(ops, dt):
     mu = torch.randn(S, n, generator=g, dtype=F64).requires_grad_()
     v = (torch.rand(S, n, generator=g, dtype=F64) + 0.1).requires_grad_()
     noise = torch.tensor(0.37, dtype=F64, requires_grad=True)
-    ref = (svgp.gauss_ell(y, mu, v, noise).sum() / (S * n))
-    ref.backward()
+    w = torch.randn(S, generator=g, dtype=F64)                       # upstream gradient per sample
+    ref = svgp.gauss_ell(y, mu, v, noise).sum(-1) / n                # (S,)
+    (ref * w).sum().backward()
     muc, vc = mu.detach().to(dt).cuda().requires_grad_(), v.detach().to(dt).cuda().requires_grad_()
     nc = noise.detach().to(dt).cuda().requires_grad_()
-    got = ops.GaussEllFn.apply(y.to(dt).cuda(), muc, vc, nc, 1.0 / (S * n))
+    got = ops.GaussEllFn.apply(y.to(dt).cuda(), muc, vc, nc, 1.0 / n)
     tol = dict(rtol=1e-11, atol=1e-12) if dt == F64 else dict(rtol=1e-4, atol=1e-5)
+    assert got.shape == (S,)
     assert torch.allclose(got.detach().cpu().double(), ref.detach(), **tol)
-    (got * 1.7).backward()
-    assert torch.allclose(muc.grad.cpu().double(), 1.7 * mu.grad, **tol)
-    assert torch.allclose(vc.grad.cpu().double(), 1.7 * v.grad, **tol)
-    assert torch.allclose(nc.grad.cpu().double(), 1.7 * noise.grad, **tol)
+    (got * w.to(dt).cuda()).sum().backward()
+    assert torch.allclose(muc.grad.cpu().double(), mu.grad, **tol)
+    assert torch.allclose(vc.grad.cpu().double(), v.grad, **tol)
+    assert torch.allclose(nc.grad.cpu().double(), noise.grad, **tol)
     # KL
     m = torch.randn(2, M, generator=g, dtype=F64).requires_grad_()
     Lq = (torch.tril(0.1 * torch.randn(2, M, M, generator=g, dtype=F64)) + torch.eye(M, dtype=F64)
