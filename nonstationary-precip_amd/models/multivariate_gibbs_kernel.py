@@ -1,0 +1,81 @@
+"""Paciorek-Schervish ("multivariate Gibbs") kernel with a matrix-normal prior on the latent H, on
+the MI355X engine -- drop-in for models/multivariate_gibbs_kernel.py of the reference.
+
+  MultivariateGibbsKernel(x, input_dim)  with .H (N,2), .D (2,2),
+      .expectation_conditional_matrix_variate_dist(x_star), .forward(x1, x2, diag=False)   ref :20-150
+  Sigma_i = softplus((h_i h_i^T)**2) + D**2 (elementwise squares);  H enters DETACHED (ref :85,98), so
+  K has gradients w.r.t. D only.  The reference's Python loop over N through numpy and its
+  (N,N,2,2) det / inverse temporaries are one gfx950 launch with closed-form 2x2 algebra
+  (nsgp_ps2d_build_fwd).  The conditional mean kron(col, R*) kron(col^-1, R^-1) vec(H) is evaluated
+  as R* R^-1 H (identical by the mixed-product rule; no (2N*) x (2N) Kronecker matrix).
+Quirks kept (SURVEY Appendix B / DESIGN.md): `lengthscale=` passed to RBFKernel is swallowed by
+gpytorch's Kernel.__init__(**kwargs), so the row kernel really has lengthscale softplus(0); the
+cross-covariance branch decides which side carries H by comparing lengths.  The reference's
+`print` on the cross branch is dropped.
+"""
+import torch
+
+import nsgp.gp as gpytorch
+from nsgp import ops
+from nsgp.gp.kernels import RBFKernel, ScaleKernel, same_points
+from models.latent_priors import MatrixVariateNormalPrior
+
+jitter = 1e-5
+softplus = torch.nn.Softplus()
+
+
+def _sigma(H, D):
+    """(n,2,2): softplus((h h^T)**2) + D**2 -- O(n) elementwise host glue."""
+    outer = H.unsqueeze(-1) * H.unsqueeze(-2)
+    return softplus(outer ** 2) + D ** 2
+
+
+class MultivariateGibbsKernel(gpytorch.kernels.Kernel):
+    is_stationary = False
+
+    def __init__(self, x, input_dim, **kwargs):
+        super().__init__(**kwargs)
+        self.x = x
+        self.n = len(x)
+        self.d = input_dim
+        if input_dim == 1:
+            raise ValueError('Use gibbs 1d kernel for dim 1')
+        self.row_covar_kernel = RBFKernel(ard_num_dims=self.d, lengthscale=torch.Tensor([0.2, 0.2])).to(x.device)
+        self.row_covar_kernel.requires_grad_(False)
+        self.loc = torch.zeros(self.n, self.d, device=x.device)
+        self.row_covar = self.row_covar_kernel(self.x).evaluate()
+        self.col_covar = torch.tensor([[5., 0.], [0., 5.]], device=x.device)
+        self.H_matrix_prior = MatrixVariateNormalPrior(self.loc, row_covariance_matrix=self.row_covar,
+                                                       column_covariance_matrix=self.col_covar)
+        H_init = self.H_matrix_prior.sample_n(1)
+        self.register_parameter(name='H', parameter=torch.nn.Parameter(H_init.to(torch.float32)))
+        self.register_prior('prior_H', self.H_matrix_prior, 'H')
+        D_init = torch.diag(torch.randn(2))
+        self.register_parameter(name='D', parameter=torch.nn.Parameter(D_init.to(torch.float32).to(x.device)))
+
+    def _row_solve(self):
+        """(row + jitter I)^-1 H with the prior's cached GPU inverse."""
+        return ops.gemm(self.prior_H.row_inv.to(self.H.dtype), self.H.detach().contiguous())
+
+    def expectation_conditional_matrix_variate_dist(self, x_star):
+        cross = self.row_covar_kernel(x_star, self.x).evaluate()            # (N*, N)
+        return ops.gemm(cross.contiguous(), self._row_solve())              # (N*, D)
+
+    def _latent(self, x1, x2):
+        H = self.H.detach()
+        if same_points(x1, x2):
+            Hx = H if len(x1) == H.shape[0] else self.expectation_conditional_matrix_variate_dist(x1).detach()
+            return Hx, Hx
+        if x1.shape[0] == H.shape[0]:
+            return H, self.expectation_conditional_matrix_variate_dist(x2).detach()
+        if x2.shape[0] == H.shape[0]:
+            return self.expectation_conditional_matrix_variate_dist(x1).detach(), H
+        raise ValueError('neither input has as many rows as the latent H')
+
+    def forward(self, x1, x2, diag=False, **params):
+        H1, H2 = self._latent(x1, x2)
+        s1 = _sigma(H1, self.D)
+        s2 = s1 if H2 is H1 else _sigma(H2, self.D)
+        self.sigma_matrix_i, self.sigma_matrix_j = s1, s2
+        K = ops.ps2d_kernel(x1, x2, s1, s2, jitter)
+        return torch.diagonal(K, dim1=-1, dim2=-2) if diag else K

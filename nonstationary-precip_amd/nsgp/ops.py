@@ -478,6 +478,7 @@ class GibbsKernelFn(torch.autograd.Function):
     def forward(ctx, x1, x2, ell1, ell2, outputscale, diag_add):
         ctx.save_for_backward(x1, x2, ell1, ell2, outputscale)
         ctx.has_diag = diag_add is not None
+        ctx.diag_shape = diag_add.shape if torch.is_tensor(diag_add) else None
         return gibbs_build(x1, x2, ell1, ell2, outputscale, diag_add)
 
     @staticmethod
@@ -487,7 +488,7 @@ class GibbsKernelFn(torch.autograd.Function):
         g_l1, g_l2, g_x1, g_x2, g_os = gibbs_build_bwd(x1, x2, ell1, ell2, outputscale, G, need_x=need_x)
         g_diag = None
         if ctx.has_diag and ctx.needs_input_grad[5]:
-            g_diag = torch.diagonal(G).sum().reshape(())
+            g_diag = torch.diagonal(G).sum().reshape(ctx.diag_shape if ctx.diag_shape is not None else ())
         g_osr = None
         if outputscale is not None and ctx.needs_input_grad[4]:
             g_osr = g_os.reshape(outputscale.shape)

@@ -1,0 +1,273 @@
+"""GPU parity of the reference-facing models.* classes against the CPU oracle on the bundled CSVs
+(BASELINE configs 0-2 at their real sizes): objective values, gradients, posterior means / variances.
+Set-up mirrors experiments/spatial_exp.py:136-201 and experiments/seard_spatial_benchmark.py:40-88.
+Tolerances: float64 models 1e-8 relative, float32 models 1e-4 relative on the posterior mean
+(the north-star bound), stated at each assert."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+F64 = torch.float64
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+
+
+def _uib_spatial(data_dir, seed=173):
+    """experiments/spatial_exp.py:35-39,136-150: float64, z-scored, seed-173 shuffled 80/20 split."""
+    import pandas as pd
+    df = pd.read_csv(os.path.join(data_dir, 'uib_spatial.csv'), dtype=np.float64)
+    arr = torch.tensor(np.array(df)).double()
+    x, y = arr[:, 0:2], arr[:, -1]
+    stdx, meanx = torch.std_mean(x, dim=-2)
+    stdy, meany = torch.std_mean(y)
+    xn, yn = (x - meanx) / stdx, (y - meany) / stdy
+    rng = np.random.default_rng(seed)
+    idx = np.arange(y.shape[0])
+    rng.shuffle(idx)
+    ntr = math.ceil(0.8 * y.shape[0])
+    tr, te = idx[:ntr], idx[ntr:]
+    return xn[tr], yn[tr], xn[te], yn[te]
+
+
+def _prior(device, dtype=F64):
+    from models.gibbs_kernels import LogNormalPriorProcess
+    prior = LogNormalPriorProcess(input_dim=2).to(device)
+    prior.covar_module.outputscale = 1.0 * torch.ones_like(prior.covar_module.outputscale)
+    prior.covar_module.base_kernel.lengthscale = 1.3 * torch.ones_like(prior.covar_module.base_kernel.lengthscale)
+    prior.mean_module.constant = torch.nn.Parameter(math.log(0.3) * torch.ones_like(prior.mean_module.constant))
+    for p in prior.parameters():
+        p.requires_grad = False
+    return prior
+
+
+def _oracle_prior():
+    from oracle import exact
+    return exact.LogNormalPrior(torch.full((2,), math.log(0.3), dtype=F64), torch.full((2, 2), 1.3, dtype=F64),
+                                torch.ones(2, dtype=F64))
+
+
+def test_lognormal_prior_process_matches_oracle(data_dir):
+    _need_gpu()
+    xtr, ytr, xte, yte = _uib_spatial(data_dir)
+    prior = _prior('cuda').double()
+    opr = _oracle_prior()
+    g = torch.Generator().manual_seed(1)
+    log_ell = 0.2 * torch.randn(2, len(xtr), generator=g, dtype=F64) + math.log(0.3)
+    lp = prior.log_prob((xtr.cuda(), log_ell.cuda()))
+    assert torch.allclose(lp.cpu(), opr.log_prob(xtr, log_ell), rtol=1e-7, atol=1e-9)     # kappa(K + 1e-4 I) ~ 1e7
+    cond = prior.conditional_sample(xte.cuda(), given=(xtr.cuda(), torch.exp(log_ell).cuda()))
+    assert cond.shape == (2, len(xte))
+    assert torch.allclose(cond.cpu(), opr.conditional_mean_ell(xte, xtr, torch.exp(log_ell)), rtol=1e-8, atol=1e-10)
+    dist = prior.forward(xtr.cuda())
+    assert dist.mean.shape == (2, len(xtr)) and dist.covariance_matrix.shape == (2, len(xtr), len(xtr))
+
+
+def test_diagonal_exact_gp_objective_gradient_and_predict(data_dir):
+    """BASELINE config 1 (GibbsKernel 2D exact GP on uib_spatial, N=394: 316 train / 78 test), float64."""
+    _need_gpu()
+    import nsgp.gp as gpytorch
+    from models.nonstationary_models import DiagonalExactGP
+    from oracle import exact
+    xtr, ytr, xte, yte = _uib_spatial(data_dir)
+    assert len(xtr) == 316 and len(xte) == 78
+    prior = _prior('cpu')
+    likelihood = gpytorch.likelihoods.GaussianLikelihood().double()
+    model = DiagonalExactGP(xtr, ytr, likelihood, prior, num_dim=2).to('cuda').double()
+    model.likelihood.noise = 0.011
+    model.covar_module.outputscale = 0.644
+    g = torch.Generator().manual_seed(2)
+    with torch.no_grad():
+        model.log_ell_train_x.add_(0.2 * torch.randn(2, 316, generator=g, dtype=F64).cuda())
+    assert 'log_ell_train_x' in dict(model.named_parameters())
+    model.train()
+    likelihood.train()
+    mll = gpytorch.mlls.ExactMarginalLogLikelihood(likelihood, model)
+    out = model(model.train_inputs[0])
+    val = mll(out, model.train_targets)
+    val.backward()
+
+    log_ell = model.log_ell_train_x.detach().cpu().clone().requires_grad_()
+    ref = exact.gibbs_exact_mll(xtr, ytr, log_ell, 0.644, 0.011, _oracle_prior())
+    ref.backward()
+    assert abs(float(val) - float(ref)) < 1e-7 * abs(float(ref))
+    assert torch.allclose(model.log_ell_train_x.grad.cpu(), log_ell.grad, rtol=1e-6, atol=1e-9)
+
+    model.eval()
+    with torch.no_grad():
+        pred = model.predict(xte.cuda())
+        mu_r, cov_r, _ = exact.gibbs_exact_predict(xtr, ytr, log_ell.detach(), 0.644, 0.011, _oracle_prior(), xte)
+    rel = float((pred.loc.cpu() - mu_r).norm() / mu_r.norm())
+    assert rel < 1e-8, rel                                    # posterior mean
+    assert torch.allclose(pred.covariance_matrix.cpu(), cov_r, rtol=1e-6, atol=1e-9)
+    assert torch.allclose(torch.diagonal(pred.covariance_matrix).cpu(), torch.diagonal(cov_r), rtol=1e-7, atol=1e-10)
+    lp = pred.log_prob(yte.cuda())
+    lp_ref = exact.mvn_log_prob(yte, mu_r, cov_r)
+    assert abs(float(lp) - float(lp_ref)) < 1e-6 * abs(float(lp_ref))
+
+
+def test_training_mode_requires_the_training_inputs(data_dir):
+    _need_gpu()
+    import nsgp.gp as gpytorch
+    from models.nonstationary_models import DiagonalExactGP
+    xtr, ytr, xte, _ = _uib_spatial(data_dir)
+    model = DiagonalExactGP(xtr, ytr, gpytorch.likelihoods.GaussianLikelihood().double(), _prior('cpu'),
+                            num_dim=2).to('cuda').double()
+    model.train()
+    with pytest.raises(RuntimeError, match='You must train on the training inputs'):
+        model(xte.cuda())
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+def test_seard_exact_gp_matches_oracle_and_sklearn_path(data_dir, dtype):
+    """BASELINE config 0 family: ExactGPModel(ScaleKernel(RBF-ARD)) on uib_spatial, whitened, ordered split
+    (experiments/seard_spatial_benchmark.py:40-106)."""
+    _need_gpu()
+    import nsgp.gp as gpytorch
+    import models.dgps as m
+    import utils.dataprep as dp
+    from oracle import exact
+    data = dp.download_data(os.path.join(data_dir, 'uib_spatial.csv')).to(dtype)
+    x, y, *_ = dp.whitening_transform(data)
+    trx, try_, tex, tey = dp.train_test_split(x, y, 0.8)
+    likelihood = gpytorch.likelihoods.GaussianLikelihood()
+    kernel = gpytorch.kernels.ScaleKernel(gpytorch.kernels.RBFKernel(ard_num_dims=2))
+    model = m.ExactGPModel(trx, try_, likelihood, kernel).to(dtype).cuda()
+    model.likelihood.noise = 0.05
+    kernel.outputscale = 0.644
+    kernel.base_kernel.lengthscale = torch.tensor([[0.7, 0.9]])
+    model.mean_module.constant.data.fill_(0.1)
+    model.train()
+    mll = gpytorch.mlls.ExactMarginalLogLikelihood(likelihood, model)
+    val = mll(model(model.train_inputs[0]), model.train_targets)
+    val.backward()
+    ls = torch.tensor([[0.7, 0.9]], dtype=F64)
+    c = torch.tensor([0.1], dtype=F64)
+    ref = exact.seard_mll(trx.double(), try_.double(), ls, 0.644, 0.05, c)
+    tol = 1e-6 if dtype == F64 else 2e-4
+    assert abs(float(val) - float(ref)) < tol * abs(float(ref))
+    assert all(p.grad is not None for p in model.parameters())
+    model.eval()
+    with torch.no_grad():
+        pred = likelihood(model(tex.cuda()))
+    m_ref, c_ref = exact.seard_predict(trx.double(), try_.double(), ls, 0.644, 0.05, c, tex.double())
+    rel = float((pred.loc.cpu().double() - m_ref).norm() / m_ref.norm())
+    assert rel < (1e-9 if dtype == F64 else 1e-4), rel        # north-star: posterior mean within 1e-4
+    v = torch.diagonal(pred.covariance_matrix).cpu().double()
+    assert torch.allclose(v, torch.diagonal(c_ref), rtol=1e-7 if dtype == F64 else 2e-3, atol=1e-9 if dtype == F64 else 1e-5)
+
+
+def test_khyber_time_series_plumbing(data_dir):
+    """BASELINE config 0: stationary exact GP on khyber_time_series.csv (N=342, 274 train), plumbing."""
+    _need_gpu()
+    import nsgp.gp as gpytorch
+    import models.dgps as m
+    import utils.dataprep as dp
+    from oracle import exact
+    data = dp.download_data(os.path.join(data_dir, 'khyber_time_series.csv'))
+    x, y, *_ = dp.whitening_transform(data)
+    trx, try_, tex, tey = dp.train_test_split(x, y, 0.8)
+    assert len(trx) == 273 or len(trx) == 274
+    likelihood = gpytorch.likelihoods.GaussianLikelihood()
+    kernel = gpytorch.kernels.ScaleKernel(gpytorch.kernels.RBFKernel())
+    model = m.ExactGPModel(trx, try_, likelihood, kernel).cuda()
+    model.train()
+    mll = gpytorch.mlls.ExactMarginalLogLikelihood(likelihood, model)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01)
+    losses = []
+    for _ in range(5):
+        opt.zero_grad()
+        loss = -mll(model(model.train_inputs[0]), model.train_targets)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0]
+    ls0 = torch.nn.functional.softplus(torch.zeros(1, 1, dtype=F64))
+    ref0 = -exact.seard_mll(trx.double(), try_.double(), ls0, float(ls0), float(ls0) + 1e-4,
+                            torch.zeros(1, dtype=F64))
+    assert abs(losses[0] - float(ref0)) < 5e-4 * abs(float(ref0))
+
+
+def test_diagonal_sparse_gp_objective_and_predict(data_dir):
+    """SGPR over the Gibbs kernel (models/nonstationary_models.py:64-153), M=60 k-means centres."""
+    _need_gpu()
+    import nsgp.gp as gpytorch
+    from sklearn.cluster import KMeans
+    from models.nonstationary_models import DiagonalSparseGP
+    from oracle import sparse
+    xtr, ytr, xte, yte = _uib_spatial(data_dir)
+    z = torch.tensor(KMeans(60, n_init=2, random_state=0).fit(xtr.numpy()).cluster_centers_).double()
+    likelihood = gpytorch.likelihoods.GaussianLikelihood().double()
+    model = DiagonalSparseGP(xtr, ytr, likelihood, _prior('cpu'), z, num_dim=2).to('cuda').double()
+    model.likelihood.noise = 0.05
+    model.covar_module.outputscale = 0.644
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        model.log_ell_z.add_(0.1 * torch.randn(2, 60, generator=g, dtype=F64).cuda())
+    model.train()
+    mll = gpytorch.mlls.ExactMarginalLogLikelihood(likelihood, model)
+    val = mll(model(model.train_inputs[0]), model.train_targets)
+    val.backward()
+    le = model.log_ell_z.detach().cpu().clone().requires_grad_()
+    zo = z.clone().requires_grad_()
+    ref = sparse.sgpr_mll(xtr, ytr, zo, le, 0.644, 0.05, _oracle_prior())
+    ref.backward()
+    assert abs(float(val) - float(ref)) < 1e-7 * abs(float(ref))
+    assert torch.allclose(model.log_ell_z.grad.cpu(), le.grad, rtol=1e-5, atol=1e-8)
+    assert torch.allclose(model.covar_module.base_kernel.inducing_points.grad.cpu(), zo.grad, rtol=1e-5, atol=1e-8)
+    with pytest.raises(RuntimeError, match='x1 should equal x2 in training mode'):
+        model.covar_module(xtr.cuda(), xte.cuda(), ell=torch.exp(model.log_ell_z)).evaluate()
+    model.eval()
+    with torch.no_grad():
+        pred = model.predict(xte.cuda())
+        m_ref, c_ref = sparse.sgpr_predict(xtr, ytr, z, le.detach(), 0.644, 0.05, _oracle_prior(), xte)
+    rel = float((pred.loc.cpu() - m_ref).norm() / m_ref.norm())
+    assert rel < 1e-7, rel
+    assert torch.allclose(torch.diagonal(pred.covariance_matrix).cpu(), torch.diagonal(c_ref), rtol=1e-5, atol=1e-8)
+
+
+def test_multivariate_gibbs_kernels_match_oracle(data_dir):
+    """models.multivariate_gibbs_kernel / sparse_multivariate_gibbs_kernel vs oracle.psgibbs (float32)."""
+    _need_gpu()
+    from models.multivariate_gibbs_kernel import MultivariateGibbsKernel
+    from models.sparse_multivariate_gibbs_kernel import SparseMultivariateGibbsKernel
+    from oracle import psgibbs
+    xtr, ytr, xte, yte = _uib_spatial(data_dir)
+    x, xs = xtr[:200].float().cuda(), xte[:50].float().cuda()
+    with pytest.raises(ValueError, match='Use gibbs 1d kernel for dim 1'):
+        MultivariateGibbsKernel(x, 1)
+    torch.manual_seed(0)
+    k = MultivariateGibbsKernel(x, 2)
+    assert k.H.shape == (200, 2) and k.D.shape == (2, 2)
+    ls = torch.full((1, 2), math.log(2.0), dtype=F64)            # softplus(0): `lengthscale=` kwarg is swallowed
+    col = 5.0 * torch.eye(2, dtype=F64)
+    H, Dm = k.H.detach().cpu().double(), k.D.detach().cpu().double()
+    xd, xsd = x.cpu().double(), xs.cpu().double()
+    Kxx = k(x).evaluate()
+    ref = psgibbs.mv_gibbs_forward(xd, xd, xd, H, Dm, ls, col)
+    assert torch.allclose(Kxx.cpu().double(), ref, rtol=2e-4, atol=2e-5)
+    Ksx = k(xs, x).evaluate()
+    Hs = k.expectation_conditional_matrix_variate_dist(xs)
+    Hs_ref = psgibbs.conditional_H(xsd, xd, H, ls, col)
+    assert torch.allclose(Hs.cpu().double(), Hs_ref, rtol=5e-3, atol=5e-3)
+    ref_sx = psgibbs.mv_gibbs_forward(xsd, xd, xd, H, Dm, ls, col)
+    assert torch.allclose(Ksx.cpu().double(), ref_sx, rtol=5e-3, atol=5e-3)
+    # gradient reaches D only (H is detached inside the kernel, reference :85,98)
+    Kxx.sum().backward()
+    assert k.D.grad is not None and (k.H.grad is None or float(k.H.grad.abs().max()) == 0.0)
+    # sparse variant: H at M inducing locations
+    Z = x[:40].clone()
+    ks = SparseMultivariateGibbsKernel(Z, 2, Z.clone())
+    Kn = ks(x).evaluate()
+    lsd = torch.full((1, 2), math.log(2.0), dtype=F64)
+    refn = psgibbs.mv_gibbs_forward(xd, xd, Z.cpu().double(), ks.H.detach().cpu().double(),
+                                    ks.D.detach().cpu().double(), lsd, torch.eye(2, dtype=F64), row_os=math.log(2.0))
+    assert torch.allclose(Kn.cpu().double(), refn, rtol=5e-3, atol=5e-3)
+    prior_lp = ks.prior_H.log_prob(ks.H)
+    assert torch.isfinite(prior_lp)
