@@ -48,127 +48,181 @@ template <> int gemm_t<double>(int64_t M, int64_t N, int64_t K, double alpha, co
                          nb2, flags | NSGP_GEMM_NO_SPLITK, nullptr, 0, stream);
 }
 
-// Factor the nb x nb lower block held in D (LDS, leading dim LDD) in place.  All 256 threads.
-// Returns (to every thread) 0 or the 1-based index of the first non-positive pivot.
-template <typename T> __device__ int factor_block(T* D, int nb, int* s_info) {
-    const int tid = threadIdx.x;
-    if (tid == 0) *s_info = 0;
-    for (int k = 0; k < nb; ++k) {
-        __syncthreads();
-        const T dkk = D[k * LDD + k];
-        if (tid == 0 && !(dkk > T(0)) && *s_info == 0) *s_info = k + 1;
-        const T piv = t_sqrt(dkk);
+// ---- wave-level 64x64 building blocks ------------------------------------------------------------
+// One wave owns a 64x64 block with ONE ROW PER LANE in registers (a[j] = element (lane, j)); values
+// of another row are broadcast with v_readlane (lane index is a compile-time constant after full
+// unrolling), so the whole factorisation is straight-line VALU code: no LDS, no barriers.
+__device__ __forceinline__ float bcast(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ __forceinline__ double bcast(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// In-register Cholesky of the block (right-looking by columns).  On exit a[j] (j <= lane) is L[lane][j],
+// a[j] (j > lane) is 0.  Returns 0 or the 1-based index of the first non-positive pivot (wave-uniform).
+template <typename T> __device__ __forceinline__ int factor_rows(T (&a)[NB], int lane) {
+    int bad = 0;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const T akk = bcast(a[k], k);
+        if (!(akk > T(0)) && bad == 0) bad = k + 1;
+        const T piv = t_sqrt(akk);
         const T inv = T(1) / piv;
-        __syncthreads();
-        if (tid == k) D[k * LDD + k] = piv;
-        else if (tid > k && tid < nb) D[tid * LDD + k] *= inv;
-        __syncthreads();
-        const int rem = nb - k - 1;
-        for (int e = tid; e < rem * rem; e += 256) {
-            const int i = k + 1 + e / rem, j = k + 1 + e % rem;
-            if (j <= i) D[i * LDD + j] -= D[i * LDD + k] * D[j * LDD + k];
-        }
+        const T lik = lane == k ? piv : (lane > k ? a[k] * inv : T(0));
+        a[k] = lik;
+#pragma unroll
+        for (int j = k + 1; j < NB; ++j) a[j] -= lik * bcast(lik, j);      // a[j] -= L[i][k] * L[j][k]
     }
-    __syncthreads();
-    return *s_info;
+    return bad;
 }
 
-// X = D^-1 for the nb x nb lower-triangular block D (LDS) into Li (LDS); strict upper of Li zeroed.
-template <typename T> __device__ void invert_block(const T* D, T* Li, int nb) {
-    const int c = threadIdx.x;
-    if (c < nb) {
-        for (int i = 0; i < c; ++i) Li[i * LDD + c] = T(0);
-        Li[c * LDD + c] = T(1) / D[c * LDD + c];
-        for (int i = c + 1; i < nb; ++i) {
-            T s = T(0);
-            for (int k = c; k < i; ++k) s += D[i * LDD + k] * Li[k * LDD + c];
-            Li[i * LDD + c] = -s / D[i * LDD + i];
-        }
+// Column `lane` of X = L^-1 for the lower-triangular block whose row `lane` is a[]:  x[i] = X[i][lane].
+template <typename T> __device__ __forceinline__ void invert_rows(const T (&a)[NB], T (&x)[NB], int lane) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        T acc = lane == i ? T(1) : T(0);
+#pragma unroll
+        for (int k = 0; k < i; ++k) acc -= bcast(a[k], i) * x[k];            // L[i][k] * X[k][lane]
+        x[i] = i < lane ? T(0) : acc / bcast(a[i], i);                      // exact zeros above the diagonal
     }
-    __syncthreads();
 }
 
-// grid.x = nslab + 1: blocks [0, nslab) each own a 64-row slab of the panel below the diagonal block
-// (block 0 also publishes the factor), the last block writes panel j-1's factor back into A.
+// Ragged tail (nb < 64): same algorithm with the block in LDS (lane i owns row i) and run-time loop
+// bounds; the lane index of v_readlane is a wave-uniform loop counter.  Only the last panel of a matrix
+// whose order is not a multiple of 64 takes this path.
+template <typename T> __device__ __forceinline__ T bcast_dyn(T v, int l);
+template <> __device__ __forceinline__ float bcast_dyn<float>(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), __builtin_amdgcn_readfirstlane(l)));
+}
+template <> __device__ __forceinline__ double bcast_dyn<double>(double v, int l) {
+    const int ul = __builtin_amdgcn_readfirstlane(l);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), ul);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), ul);
+    return __hiloint2double(hi, lo);
+}
+
+template <typename T> __device__ int factor_lds(T* Ls, int nb, int lane) {
+    int bad = 0;
+    const bool live = lane < nb;
+    for (int k = 0; k < nb; ++k) {
+        const T aik = live ? Ls[lane * LDD + k] : T(0);
+        const T akk = bcast_dyn<T>(aik, k);
+        if (!(akk > T(0)) && bad == 0) bad = k + 1;
+        const T piv = t_sqrt(akk);
+        const T inv = T(1) / piv;
+        const T lik = lane == k ? piv : (lane > k ? aik * inv : T(0));
+        if (live) Ls[lane * LDD + k] = lik;
+        for (int j = k + 1; j < nb; ++j) {
+            const T ljk = bcast_dyn<T>(lik, j);
+            if (live) Ls[lane * LDD + j] -= lik * ljk;
+        }
+    }
+    return bad;
+}
+
+// write-back of panel p's factor (side buffer -> A) + zero the strict upper part of its rows
 template <typename T>
-__global__ __launch_bounds__(256) void potrf_panel_kernel(T* __restrict__ A, int64_t n, int64_t lda, int64_t sA,
-                                                          int64_t j0, T* __restrict__ wsL, int64_t npanels,
-                                                          int32_t* __restrict__ info) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* D = reinterpret_cast<T*>(smem_raw);
-    T* Li = D + NB * LDD;
-    T* S = Li + NB * LDD;
-    int* s_info = reinterpret_cast<int*>(S + NB * LDD);      // all LDS in the one dynamic region
-    const int tid = threadIdx.x;
+__device__ __forceinline__ void writeback_panel(T* Ab, int64_t n, int64_t lda, const T* src, int64_t p, int lane) {
+    const int64_t r0 = p * NB;
+    const int pnb = (int)((n - r0) < NB ? (n - r0) : NB);
+    for (int i = 0; i < pnb; ++i) {
+        if (lane <= i) Ab[(r0 + i) * lda + r0 + lane] = src[i * NB + lane];
+        for (int64_t c = r0 + i + 1 + lane; c < n; c += 64) Ab[(r0 + i) * lda + c] = T(0);
+    }
+}
+
+// FULL 64-wide panel.  grid.x = nslab + 1 one-wave workgroups: blocks [0, nslab) each factor the diagonal
+// block in registers (redundantly: ~10 us of VALU, no grid-wide dependency) and solve their own
+// 64-row slab of the panel, L21 = A21 L11^-T, by forward substitution with L11 broadcast from LDS;
+// block 0 publishes L11 to the side buffer; the last block writes panel j-1's factor back into A.
+template <typename T>
+__global__ __launch_bounds__(64) void potrf_panel_kernel(T* __restrict__ A, int64_t n, int64_t lda, int64_t sA,
+                                                         int64_t j0, T* __restrict__ wsL, int64_t npanels,
+                                                         int32_t* __restrict__ info) {
+    __shared__ T Ls[NB * LDD];
+    const int lane = threadIdx.x;
     const int64_t b = blockIdx.y;
     T* Ab = A + b * sA;
     const int64_t pj = j0 / NB;
     const int nslab = (int)gridDim.x - 1;
-
     if ((int)blockIdx.x == nslab) {
-        // write-back of the previous panel (nobody reads its A11 any more)
-        const int64_t p = pj - 1;
-        if (p < 0) return;
-        const int64_t r0 = p * NB;
-        const int pnb = (int)((n - r0) < NB ? (n - r0) : NB);
-        const T* src = wsL + (b * npanels + p) * NB * NB;
-        for (int e = tid; e < pnb * pnb; e += 256) {
-            const int i = e / pnb, j = e % pnb;
-            if (j <= i) Ab[(r0 + i) * lda + r0 + j] = src[i * NB + j];
-        }
-        for (int i = 0; i < pnb; ++i)
-            for (int64_t c = r0 + i + 1 + tid; c < n; c += 256) Ab[(r0 + i) * lda + c] = T(0);
+        if (pj > 0) writeback_panel(Ab, n, lda, wsL + (b * npanels + pj - 1) * NB * NB, pj - 1, lane);
         return;
     }
-
-    const int nb = (int)((n - j0) < NB ? (n - j0) : NB);
-    for (int e = tid; e < nb * nb; e += 256) {
-        const int i = e / nb, j = e % nb;
-        D[i * LDD + j] = (j <= i) ? Ab[(j0 + i) * lda + j0 + j] : T(0);
-    }
-    const int bad = factor_block(D, nb, s_info);
-    if (blockIdx.x == 0) {
-        T* dst = wsL + (b * npanels + pj) * NB * NB;
-        for (int e = tid; e < nb * nb; e += 256) dst[(e / nb) * NB + e % nb] = D[(e / nb) * LDD + e % nb];
-        if (tid == 0 && bad && info[b] == 0) info[b] = (int32_t)(j0 + bad);
-    }
-    const int64_t r0 = j0 + nb + (int64_t)blockIdx.x * NB;
-    if (r0 >= n) return;                                   // block 0 of the last panel has no slab
-    invert_block(D, Li, nb);
-    const int rows = (int)((n - r0) < NB ? (n - r0) : NB);
-    for (int e = tid; e < rows * nb; e += 256) {
-        const int i = e / nb, j = e % nb;
-        S[i * LDD + j] = Ab[(r0 + i) * lda + j0 + j];
+    int bad;
+    {
+        T a[NB];
+        const T* src = Ab + (j0 + lane) * lda + j0;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) a[j] = src[j];       // the upper part is never used (zeroed by factor_rows)
+        bad = factor_rows(a, lane);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) Ls[lane * LDD + j] = a[j];
     }
     __syncthreads();
-    // X[r][c] = sum_{k<=c} S[r][k] * Li[c][k];  thread -> 4 rows x 4 cols
-    const int tr = (tid >> 4) * 4, tc = (tid & 15) * 4;
-    T acc[4][4];
+    if (blockIdx.x == 0) {
+        T* dst = wsL + (b * npanels + pj) * NB * NB;
+        for (int i = 0; i < NB; ++i) dst[i * NB + lane] = Ls[i * LDD + lane];
+        if (lane == 0 && bad && info[b] == 0) info[b] = (int32_t)(j0 + bad);
+    }
+    const int64_t r0 = j0 + NB + (int64_t)blockIdx.x * NB;
+    if (r0 >= n) return;
+    const int rows = (int)((n - r0) < NB ? (n - r0) : NB);
+    const bool live = lane < rows;
+    T x[NB];
+    {
+        const T* src = Ab + (r0 + (live ? lane : 0)) * lda + j0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = T(0);
-    const int kmax = tc + 4 < nb ? tc + 4 : nb;
-    for (int k = 0; k < kmax; ++k) {
-        T sv[4], lv[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) sv[i] = S[(tr + i) * LDD + k];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) lv[j] = Li[(tc + j) * LDD + k];      // zero for k > c
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] += sv[i] * lv[j];
+        for (int j = 0; j < NB; ++j) x[j] = src[j];
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int c = 0; c < NB; ++c) {
+        T acc = x[c];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (tr + i < rows && tc + j < nb) Ab[(r0 + tr + i) * lda + j0 + tc + j] = acc[i][j];
+        for (int k = 0; k < c; ++k) acc -= x[k] * Ls[c * LDD + k];           // wave-uniform LDS address
+        x[c] = acc / Ls[c * LDD + c];
+    }
+    if (live) {
+        T* dst = Ab + (r0 + lane) * lda + j0;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) dst[j] = x[j];
+    }
 }
 
-template <typename T> size_t panel_lds_bytes() { return 3 * (size_t)NB * LDD * sizeof(T) + 16; }
-template <typename T> size_t diag_lds_bytes() { return 2 * (size_t)NB * LDD * sizeof(T); }
+// LAST, ragged panel (nb < 64, nothing below it): block 0 factors it in LDS, block 1 writes back panel j-1.
+template <typename T>
+__global__ __launch_bounds__(64) void potrf_tail_kernel(T* __restrict__ A, int64_t n, int64_t lda, int64_t sA,
+                                                        int64_t j0, T* __restrict__ wsL, int64_t npanels,
+                                                        int32_t* __restrict__ info) {
+    __shared__ T Ls[NB * LDD];
+    const int lane = threadIdx.x;
+    const int64_t b = blockIdx.y;
+    T* Ab = A + b * sA;
+    const int64_t pj = j0 / NB;
+    if (blockIdx.x == 1) {
+        if (pj > 0) writeback_panel(Ab, n, lda, wsL + (b * npanels + pj - 1) * NB * NB, pj - 1, lane);
+        return;
+    }
+    const int nb = (int)(n - j0);
+    if (lane < nb)
+        for (int j = 0; j <= lane; ++j) Ls[lane * LDD + j] = Ab[(j0 + lane) * lda + j0 + j];
+    const int bad = factor_lds(Ls, nb, lane);
+    T* dst = wsL + (b * npanels + pj) * NB * NB;
+    if (lane < nb)
+        for (int j = 0; j <= lane; ++j) dst[lane * NB + j] = Ls[lane * LDD + j];
+    if (lane == 0 && bad && info[b] == 0) info[b] = (int32_t)(j0 + bad);
+}
+
+// final write-back of the last panel
+template <typename T>
+__global__ __launch_bounds__(64) void potrf_writeback_kernel(T* __restrict__ A, int64_t n, int64_t lda, int64_t sA,
+                                                             const T* __restrict__ wsL, int64_t npanels) {
+    const int64_t b = blockIdx.y;
+    writeback_panel(A + b * sA, n, lda, wsL + (b * npanels + npanels - 1) * NB * NB, npanels - 1, (int)threadIdx.x);
+}
 
 template <typename T>
 int potrf_impl(T* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int32_t* info, void* ws, size_t wsb,
@@ -184,18 +238,17 @@ int potrf_impl(T* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int32_t*
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(info, 0, sizeof(int32_t) * batch, st);
     if (e != hipSuccess) return (int)e;
-    static bool attr_set = false;       // idempotent attribute, set once per process
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)potrf_panel_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)panel_lds_bytes<T>());
-        attr_set = true;
-    }
     for (int64_t j0 = 0; j0 < n; j0 += NB) {
         const int64_t nb = (n - j0) < NB ? (n - j0) : NB;
+        if (nb < NB) {
+            hipLaunchKernelGGL((potrf_tail_kernel<T>), dim3(2, (unsigned)batch), dim3(64), 0, st, A, n, lda, sA, j0,
+                               wsL, npanels, info);
+            break;
+        }
         const int64_t below = n - j0 - nb;
         const int64_t nslab = below > 0 ? cdiv64(below, NB) : 1;
-        hipLaunchKernelGGL((potrf_panel_kernel<T>), dim3((unsigned)(nslab + 1), (unsigned)batch), dim3(256),
-                           panel_lds_bytes<T>(), st, A, n, lda, sA, j0, wsL, npanels, info);
+        hipLaunchKernelGGL((potrf_panel_kernel<T>), dim3((unsigned)(nslab + 1), (unsigned)batch), dim3(64), 0, st, A,
+                           n, lda, sA, j0, wsL, npanels, info);
         if (below > 0) {
             T* L21 = A + (j0 + nb) * lda + j0;
             T* A22 = A + (j0 + nb) * lda + (j0 + nb);
@@ -204,37 +257,46 @@ int potrf_impl(T* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int32_t*
             if (rc) return rc;
         }
     }
-    // final write-back of the last panel: launch with j0 = npanels*NB so that "previous" is the last
-    hipLaunchKernelGGL((potrf_panel_kernel<T>), dim3(1, (unsigned)batch), dim3(256), panel_lds_bytes<T>(), st, A, n,
-                       lda, sA, npanels * NB, wsL, npanels, info);
+    hipLaunchKernelGGL((potrf_writeback_kernel<T>), dim3(1, (unsigned)batch), dim3(64), 0, st, A, n, lda, sA,
+                       (const T*)wsL, npanels);
     return nsgp_launch_status();
 }
 
 // ---- trtri ---------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void trtri_diag_kernel(const T* __restrict__ L, int64_t n, int64_t ldl, int64_t sL,
-                                                         T* __restrict__ X, int64_t ldx, int64_t sX) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* D = reinterpret_cast<T*>(smem_raw);
-    T* Li = D + NB * LDD;
-    const int tid = threadIdx.x;
+__global__ __launch_bounds__(64) void trtri_diag_kernel(const T* __restrict__ L, int64_t n, int64_t ldl, int64_t sL,
+                                                        T* __restrict__ X, int64_t ldx, int64_t sX) {
+    __shared__ T Ls[NB * LDD];
+    const int lane = threadIdx.x;
     const int64_t b = blockIdx.y, r0 = (int64_t)blockIdx.x * NB;
     const T* Lb = L + b * sL;
     T* Xb = X + b * sX;
     const int nb = (int)((n - r0) < NB ? (n - r0) : NB);
-    for (int e = tid; e < nb * nb; e += 256) {
-        const int i = e / nb, j = e % nb;
-        D[i * LDD + j] = (j <= i) ? Lb[(r0 + i) * ldl + r0 + j] : T(0);
-    }
-    __syncthreads();
-    invert_block(D, Li, nb);
-    for (int e = tid; e < nb * nb; e += 256) {
-        const int i = e / nb, j = e % nb;
-        Xb[(r0 + i) * ldx + r0 + j] = Li[i * LDD + j];
+    if (nb == NB) {
+        // registers: lane holds row `lane` of L, produces column `lane` of the inverse
+        T a[NB], x[NB];
+        const T* src = Lb + (r0 + lane) * ldl + r0;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) a[j] = src[j];
+        invert_rows(a, x, lane);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) Xb[(r0 + i) * ldx + r0 + lane] = x[i];       // coalesced row stores
+    } else {
+        // ragged last block: column `lane` of the inverse by forward substitution through LDS
+        T* Xs = Ls;                          // Xs[k*LDD + c] = X[k][c]; L read straight from global (small)
+        if (lane < nb) {
+            for (int i = 0; i < nb; ++i) {
+                T acc = lane == i ? T(1) : T(0);
+                for (int k = lane; k < i; ++k) acc -= Lb[(r0 + i) * ldl + r0 + k] * Xs[k * LDD + lane];
+                acc = i < lane ? T(0) : acc / Lb[(r0 + i) * ldl + r0 + i];
+                Xs[i * LDD + lane] = acc;
+                Xb[(r0 + i) * ldx + r0 + lane] = acc;
+            }
+        }
     }
     // zero everything right of the diagonal block in these rows
     for (int i = 0; i < nb; ++i)
-        for (int64_t c = r0 + nb + tid; c < n; c += 256) Xb[(r0 + i) * ldx + c] = T(0);
+        for (int64_t c = r0 + nb + lane; c < n; c += 64) Xb[(r0 + i) * ldx + c] = T(0);
 }
 
 template <typename T>
@@ -247,14 +309,8 @@ int trtri_impl(const T* L, int64_t n, int64_t ldl, int64_t sL, T* X, int64_t ldx
     if (n > NB && (!ws || wsb < need)) return -9;
     if (batch > 65535) return -8;
     hipStream_t st = (hipStream_t)stream;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)trtri_diag_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)diag_lds_bytes<T>());
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((trtri_diag_kernel<T>), dim3((unsigned)cdiv64(n, NB), (unsigned)batch), dim3(256),
-                       diag_lds_bytes<T>(), st, L, n, ldl, sL, X, ldx, sX);
+    hipLaunchKernelGGL((trtri_diag_kernel<T>), dim3((unsigned)cdiv64(n, NB), (unsigned)batch), dim3(64), 0, st, L, n,
+                       ldl, sL, X, ldx, sX);
     T* Tm = (T*)ws;                      // (batch, n, n) scratch, same indexing as X with ld = n
     for (int64_t s = NB; s < n; s *= 2) {
         // pairs (A = X[i0:i0+s, i0:i0+s], B = X[i0+s:i0+s+h, ...], C = L[i0+s:i0+s+h, i0:i0+s])
