@@ -55,19 +55,20 @@ class GemmTimer:
     def __init__(self):
         self.records = []
 
-    def __call__(self, fn, flops):
+    def __call__(self, fn, flops, dtype):
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
         out = fn()
         e1.record()
-        self.records.append((e0, e1, flops))
+        self.records.append((e0, e1, flops, dtype))
         return out
 
-    def summary(self):
+    def summary(self, dtype):
         torch.cuda.synchronize()
-        ms = sum(a.elapsed_time(b) for a, b, _ in self.records)
-        return ms, sum(f for _, _, f in self.records), len(self.records)
+        recs = [r for r in self.records if r[3] == dtype]
+        ms = sum(a.elapsed_time(b) for a, b, _, _ in recs)
+        return ms, sum(r[2] for r in recs), len(recs)
 
 
 def build(device, dp_world):
@@ -229,7 +230,8 @@ def main():
         nprof = min(args.steps, 5)
         for k in range(nprof):
             step(args.warmup + args.steps + k)
-        gemm_ms, gemm_flops, gemm_launches = timer.summary()
+        gemm_ms, gemm_flops, gemm_launches = timer.summary(torch.float32)
+        g64_ms, g64_flops, g64_launches = timer.summary(torch.float64)
         ops.set_gemm_timer(None)
 
     result = None
@@ -247,12 +249,14 @@ def main():
                        'global_batch': BATCH, 'N': N_DATA, 'parallelism': f'dp{world}',
                        'kzz_cholesky_dtype': 'f64'},
             'final_loss': round(final_loss, 5),
-            'roofline': {'bound': 'mfma', 'kernel': 'gemm_kernel<float,128,128> (all GEMM launches of a step)',
+            'roofline': {'bound': 'mfma', 'kernel': 'gemm_kernel<float,128,128,*,*> (all f32 GEMM launches of a step)',
                          'achieved': round(achieved, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
                          'gemm_ms_per_step': round(gemm_ms / nprof, 3),
                          'gemm_launches_per_step': gemm_launches // nprof,
-                         'algorithmic_gflop_per_step': round(gemm_flops / nprof / 1e9, 2)},
+                         'algorithmic_gflop_per_step': round(gemm_flops / nprof / 1e9, 2),
+                         'f64_gemm_ms_per_step': round(g64_ms / nprof, 3),
+                         'f64_gemm_launches_per_step': g64_launches // nprof},
         }
         if world == 1:
             result.update(gibbs_chol_ms(device))

@@ -126,7 +126,7 @@ int nsgp_ps2d_build_bwd_f64(const double* x1, const double* x2, const double* si
 #define NSGP_GEMM_C_LOWER  16   /* only the lower triangle (n <= m) of C is computed/stored; the
                                    strict upper triangle is written as zero when beta == 0 */
 #define NSGP_GEMM_NO_SPLITK 32  /* never split the inner dimension (no workspace needed) */
-size_t nsgp_gemm_workspace(int64_t M, int64_t N, int64_t K, int64_t nb1, int64_t nb2, int elem_size);
+size_t nsgp_gemm_workspace(int64_t M, int64_t N, int64_t K, int64_t nb1, int64_t nb2, int elem_size, int flags);
 int nsgp_gemm_f32(int64_t M, int64_t N, int64_t K, float alpha,
                   const float* A, int64_t sam, int64_t sak, int64_t sa1, int64_t sa2,
                   const float* B, int64_t sbk, int64_t sbn, int64_t sb1, int64_t sb2,

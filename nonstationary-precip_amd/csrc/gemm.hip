@@ -49,6 +49,7 @@ struct GemmArgs {
     int64_t sbk, sbn, sb1, sb2;
     int64_t ldc, sc1, sc2;
     int64_t nb2;
+    int64_t tiles_m, tiles_n;
     int64_t ksplit, kper;         // K-slices (kper is a multiple of BK)
     int64_t slab;                 // elements per (slice) slab = nb1*nb2*M*N when ksplit > 1
     int flags;
@@ -108,24 +109,34 @@ __device__ __forceinline__ Frag4<T> load_operand4(const T* base, int64_t sr, int
     return f;
 }
 
-template <typename T, int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, T alpha, const T* __restrict__ A,
+// MODE_A / MODE_B: 0 = operand contiguous along k, 1 = contiguous along m (n).
+template <typename T, int BM, int BN, int MODE_A, int MODE_B>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g, T alpha, const T* __restrict__ A,
                                                    const T* __restrict__ B, T beta, T* __restrict__ C,
                                                    T* __restrict__ slabs) {
     using MF = Mfma<T>;
     constexpr int BK = 16;
-    constexpr int MT = MF::MT, KS = MF::KS;
+    constexpr int MT = MF::MT, KS = MF::KS, NKK = BK / KS;
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int TM = WM / MT, TN = WN / MT;
     constexpr int LDA = BM + MF::PAD, LDB = BN + MF::PAD;
     constexpr int PA = BM * BK / 1024, PB = BN * BK / 1024;     // 4-element fragments per thread
+    constexpr int TPRA = BM / 4, TPRB = BN / 4;                 // threads per k-row in mode 1
     __shared__ __attribute__((aligned(32))) T As[2][BK * LDA];
     __shared__ __attribute__((aligned(32))) T Bs[2][BK * LDB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
-    const int64_t bm = blockIdx.y, bn = blockIdx.x;
-    const int64_t z = blockIdx.z;
+    // tile id -> (bm, bn): bn fastest, so the workgroups in flight share one A row panel (L2 resident) and
+    // stream disjoint B column panels.  Triangular operands make the work per tile uneven: rows with the
+    // longest K range are issued first (longest-processing-time order), which shortens the tail.
+    // (Measured on MI355X, M=1024, N=40960, K=1024 lower-triangular A: 524 us vs 577 us natural order vs
+    //  700-850 us for XCD-chunked orders, which put whole tile rows -- unequal work -- on one XCD.)
+    const int64_t tid_lin = blockIdx.x;
+    int64_t bn = tid_lin % g.tiles_n, bm = tid_lin / g.tiles_n;
+    if (g.flags & NSGP_GEMM_A_LOWER) bm = g.tiles_m - 1 - bm;          // large m = long K range
+    if (g.flags & NSGP_GEMM_B_UPPER) bn = g.tiles_n - 1 - bn;          // large n = long K range
+    const int64_t z = blockIdx.y;
     const int64_t slice = z % g.ksplit, bb = z / g.ksplit;
     const int64_t b1 = bb / g.nb2, b2 = bb % g.nb2;
     const int64_t m0 = bm * BM, n0 = bn * BN;
@@ -138,7 +149,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, T alpha, const T*
     const bool bL = g.flags & NSGP_GEMM_B_LOWER, bU = g.flags & NSGP_GEMM_B_UPPER;
     const bool cL = g.flags & NSGP_GEMM_C_LOWER;
 
-    // K range of this block: slice ∩ triangular support
+    // K range of this block: slice intersected with the triangular support
     int64_t kbeg = slice * g.kper, kend = kbeg + g.kper < g.K ? kbeg + g.kper : g.K;
     if (aL) { const int64_t e = m0 + BM; if (e < kend) kend = e; }                 // k <= m
     if (aU) { const int64_t s = m0 / BK * BK; if (s > kbeg) kbeg = s; }            // k >= m
@@ -156,50 +167,73 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, T alpha, const T*
 #pragma unroll
             for (int r = 0; r < MF::NREG; ++r) acc[i][j][r] = T(0);
 
+    // per-thread tile coordinates of its 4-element fragments
+    int ar[PA], ak[PA], br[PB], bk[PB];
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+        if (MODE_A == 0) { ar[p] = p * 64 + (tid >> 2); ak[p] = (tid & 3) * 4; }
+        else { ar[p] = (tid % TPRA) * 4; ak[p] = p * (256 / TPRA) + tid / TPRA; }
+    }
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        if (MODE_B == 0) { br[p] = p * 64 + (tid >> 2); bk[p] = (tid & 3) * 4; }
+        else { br[p] = (tid % TPRB) * 4; bk[p] = p * (256 / TPRB) + tid / TPRB; }
+    }
+    // fast path: every 16-byte fragment of the tile is in bounds, aligned and unmasked
+    const bool fastA = g.vecA && (m0 + BM <= g.M);
+    const bool fastB = g.vecB && (n0 + BN <= g.N);
+    const T* pa[PA];
+    const T* pb[PB];
+#pragma unroll
+    for (int p = 0; p < PA; ++p)
+        pa[p] = MODE_A == 0 ? Ab + (m0 + ar[p]) * g.sam + ak[p] : Ab + (m0 + ar[p]) + (int64_t)ak[p] * g.sak;
+#pragma unroll
+    for (int p = 0; p < PB; ++p)
+        pb[p] = MODE_B == 0 ? Bb + (n0 + br[p]) * g.sbn + bk[p] : Bb + (n0 + br[p]) + (int64_t)bk[p] * g.sbk;
+    const int64_t stepA = MODE_A == 0 ? 1 : g.sak, stepB = MODE_B == 0 ? 1 : g.sbk;
+
     Frag4<T> ra[PA], rb[PB];
 
     auto gload = [&](int64_t k0) {
+        const bool kfull = k0 + BK <= kend;
+        const bool a_diag = (aL || aU) && (k0 < m0 + BM) && (k0 + BK > m0);
+        const bool b_diag = (bL || bU) && (k0 < n0 + BN) && (k0 + BK > n0);
+        if (fastA && kfull && !a_diag) {
 #pragma unroll
-        for (int p = 0; p < PA; ++p) {
-            int64_t r, k;
-            if (g.modeA == 0) { r = m0 + p * 64 + (tid >> 2); k = k0 + (tid & 3) * 4; }
-            else { constexpr int TPR = BM / 4; r = m0 + (tid % TPR) * 4; k = k0 + p * (256 / TPR) + tid / TPR; }
-            ra[p] = load_operand4<T>(Ab, g.sam, g.sak, r, k, g.M, kend, g.modeA, g.vecA, aL, aU);
+            for (int p = 0; p < PA; ++p) ra[p] = ldg4(pa[p] + k0 * stepA);
+        } else {
+#pragma unroll
+            for (int p = 0; p < PA; ++p)
+                ra[p] = load_operand4<T>(Ab, g.sam, g.sak, m0 + ar[p], k0 + ak[p], g.M, kend, MODE_A, g.vecA, aL, aU);
         }
+        if (fastB && kfull && !b_diag) {
 #pragma unroll
-        for (int p = 0; p < PB; ++p) {
-            int64_t r, k;
-            if (g.modeB == 0) { r = n0 + p * 64 + (tid >> 2); k = k0 + (tid & 3) * 4; }
-            else { constexpr int TPR = BN / 4; r = n0 + (tid % TPR) * 4; k = k0 + p * (256 / TPR) + tid / TPR; }
-            // B(k,n): "lower" zero where n > k  <=> k < r ; "upper" zero where n < k <=> k > r
-            rb[p] = load_operand4<T>(Bb, g.sbn, g.sbk, r, k, g.N, kend, g.modeB, g.vecB, bU, bL);
+            for (int p = 0; p < PB; ++p) rb[p] = ldg4(pb[p] + k0 * stepB);
+        } else {
+#pragma unroll
+            for (int p = 0; p < PB; ++p)   // B(k,n): "lower" zero where n > k <=> k < r ; "upper" zero where k > r
+                rb[p] = load_operand4<T>(Bb, g.sbn, g.sbk, n0 + br[p], k0 + bk[p], g.N, kend, MODE_B, g.vecB, bU, bL);
         }
     };
     auto sstore = [&](int buf) {
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
-            if (g.modeA == 0) {
-                const int r = p * 64 + (tid >> 2), k = (tid & 3) * 4;
+            if (MODE_A == 0) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) As[buf][(k + e) * LDA + r] = ra[p].v[e];
+                for (int e = 0; e < 4; ++e) As[buf][(ak[p] + e) * LDA + ar[p]] = ra[p].v[e];
             } else {
-                constexpr int TPR = BM / 4;
-                const int r = (tid % TPR) * 4, k = p * (256 / TPR) + tid / TPR;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) As[buf][k * LDA + r + e] = ra[p].v[e];
+                for (int e = 0; e < 4; ++e) As[buf][ak[p] * LDA + ar[p] + e] = ra[p].v[e];
             }
         }
 #pragma unroll
         for (int p = 0; p < PB; ++p) {
-            if (g.modeB == 0) {
-                const int r = p * 64 + (tid >> 2), k = (tid & 3) * 4;
+            if (MODE_B == 0) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) Bs[buf][(k + e) * LDB + r] = rb[p].v[e];
+                for (int e = 0; e < 4; ++e) Bs[buf][(bk[p] + e) * LDB + br[p]] = rb[p].v[e];
             } else {
-                constexpr int TPR = BN / 4;
-                const int r = (tid % TPR) * 4, k = p * (256 / TPR) + tid / TPR;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) Bs[buf][k * LDB + r + e] = rb[p].v[e];
+                for (int e = 0; e < 4; ++e) Bs[buf][bk[p] * LDB + br[p] + e] = rb[p].v[e];
             }
         }
     };
@@ -211,21 +245,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g, T alpha, const T*
         const int kr = MF::krow(lane), mc = MF::mcol(lane);
         for (int64_t t = 0; t < nt; ++t) {
             const int buf = (int)(t & 1);
-            if (t + 1 < nt) gload(kbeg + (t + 1) * BK);
-            const T* as = &As[buf][0];
-            const T* bs = &Bs[buf][0];
+            if (t + 1 < nt) gload(kbeg + (t + 1) * BK);             // next tile -> registers (in flight)
+            const T* as = &As[buf][kr * LDA + wm0 + mc];
+            const T* bs = &Bs[buf][kr * LDB + wn0 + mc];
+            // all operand fragments of this K-tile first (LDS latency overlaps the MFMA stream) ...
+            T af[NKK][TM], bf[NKK][TN];
 #pragma unroll
-            for (int kk = 0; kk < BK / KS; ++kk) {
-                T af[TM], bf[TN];
+            for (int kk = 0; kk < NKK; ++kk) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[i] = as[(kk * KS + kr) * LDA + wm0 + i * MT + mc];
+                for (int i = 0; i < TM; ++i) af[kk][i] = as[kk * KS * LDA + i * MT];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bf[j] = bs[(kk * KS + kr) * LDB + wn0 + j * MT + mc];
+                for (int j = 0; j < TN; ++j) bf[kk][j] = bs[kk * KS * LDB + j * MT];
+            }
+            // ... then the MFMAs
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(af[i], bf[j], acc[i][j]);
-            }
+                    for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(af[kk][i], bf[kk][j], acc[i][j]);
             if (t + 1 < nt) sstore(buf ^ 1);
             __syncthreads();
         }
@@ -284,20 +322,29 @@ __global__ void splitk_reduce_kernel(GemmArgs g, T alpha, const T* __restrict__ 
 
 struct Plan { int big; int64_t ksplit, kper; };
 
+static inline int64_t active_tiles(int64_t M, int64_t N, int64_t bm, int flags) {
+    const int64_t tm = cdiv64(M, bm), tn = cdiv64(N, bm);
+    if (!(flags & NSGP_GEMM_C_LOWER)) return tm * tn;
+    int64_t cnt = 0;                                  // tiles with n0 <= m0 + bm - 1
+    for (int64_t i = 0; i < tm; ++i) cnt += (i + 1 < tn ? i + 1 : tn);
+    return cnt;
+}
+
 template <typename T> Plan make_plan(int64_t M, int64_t N, int64_t K, int64_t nb, int flags) {
     Plan p;
     const bool can_split = !(flags & NSGP_GEMM_NO_SPLITK) && K >= 512;
     int64_t maxks = can_split ? K / 256 : 1;
     if (maxks > 64) maxks = 64;
     if (maxks < 1) maxks = 1;
-    const int64_t tiles_big = cdiv64(M, 128) * cdiv64(N, 128) * nb;
+    const int64_t tiles_big = active_tiles(M, N, 128, flags) * nb;
     // 128x128 tiles (f32 only) when, with K-splitting, they still fill the 256 CUs
     p.big = sizeof(T) == 4 && tiles_big * maxks >= 256;
     const int64_t bm = p.big ? 128 : 64;
-    const int64_t tiles = cdiv64(M, bm) * cdiv64(N, bm) * nb;
+    const int64_t tiles = active_tiles(M, N, bm, flags) * nb;
     int64_t ks = 1;
-    if (tiles < 512) {
-        ks = cdiv64(512, tiles);
+    const int64_t target = p.big ? 768 : 1024;        // ~3 (4) resident workgroups per CU
+    if (tiles < target) {
+        ks = cdiv64(target, tiles);
         if (ks > maxks) ks = maxks;
     }
     p.kper = cdiv64(cdiv64(K, ks), 16) * 16;
@@ -342,14 +389,26 @@ int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam,
     }
     hipStream_t st = (hipStream_t)stream;
     const int64_t bmn = p.big ? 128 : 64;
-    dim3 grid((unsigned)cdiv64(N, bmn), (unsigned)cdiv64(M, bmn), (unsigned)(nb * g.ksplit));
-    if (grid.y > 65535 || grid.z > 65535) return -24;
+    g.tiles_m = cdiv64(M, bmn);
+    g.tiles_n = cdiv64(N, bmn);
+    if (g.tiles_m * g.tiles_n > 2147483647LL || nb * g.ksplit > 65535) return -24;
+    dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)(nb * g.ksplit), 1);
+#define NSGP_LAUNCH(BMN, MA, MB)                                                                          \
+    hipLaunchKernelGGL((gemm_kernel<T, BMN, BMN, MA, MB>), grid, dim3(256), 0, st, g, alpha, A, B, beta, C, slabs)
+#define NSGP_LAUNCH_MODES(BMN)                                                 \
+    do {                                                                       \
+        if (g.modeA == 0 && g.modeB == 0) NSGP_LAUNCH(BMN, 0, 0);              \
+        else if (g.modeA == 0) NSGP_LAUNCH(BMN, 0, 1);                         \
+        else if (g.modeB == 0) NSGP_LAUNCH(BMN, 1, 0);                         \
+        else NSGP_LAUNCH(BMN, 1, 1);                                           \
+    } while (0)
     if (p.big) {
-        if constexpr (sizeof(T) == 4)
-            hipLaunchKernelGGL((gemm_kernel<T, 128, 128>), grid, dim3(256), 0, st, g, alpha, A, B, beta, C, slabs);
+        if constexpr (sizeof(T) == 4) NSGP_LAUNCH_MODES(128);
     } else {
-        hipLaunchKernelGGL((gemm_kernel<T, 64, 64>), grid, dim3(256), 0, st, g, alpha, A, B, beta, C, slabs);
+        NSGP_LAUNCH_MODES(64);
     }
+#undef NSGP_LAUNCH_MODES
+#undef NSGP_LAUNCH
     if (g.ksplit > 1) {
         const int64_t tot = nb * M * N;
         hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, st, g, alpha,
@@ -362,10 +421,10 @@ int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam,
 
 extern "C" {
 
-size_t nsgp_gemm_workspace(int64_t M, int64_t N, int64_t K, int64_t nb1, int64_t nb2, int elem_size) {
+size_t nsgp_gemm_workspace(int64_t M, int64_t N, int64_t K, int64_t nb1, int64_t nb2, int elem_size, int flags) {
     if (M <= 0 || N <= 0 || K <= 0 || nb1 < 1 || nb2 < 1) return 0;
     const int64_t nb = nb1 * nb2;
-    const Plan p = elem_size == 4 ? make_plan<float>(M, N, K, nb, 0) : make_plan<double>(M, N, K, nb, 0);
+    const Plan p = elem_size == 4 ? make_plan<float>(M, N, K, nb, flags) : make_plan<double>(M, N, K, nb, flags);
     return p.ksplit > 1 ? (size_t)p.ksplit * nb * M * N * elem_size : 0;
 }
 

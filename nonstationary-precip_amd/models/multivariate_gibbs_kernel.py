@@ -54,8 +54,14 @@ class MultivariateGibbsKernel(gpytorch.kernels.Kernel):
         self.register_parameter(name='D', parameter=torch.nn.Parameter(D_init.to(torch.float32).to(x.device)))
 
     def _row_solve(self):
-        """(row + jitter I)^-1 H with the prior's cached GPU inverse."""
-        return ops.gemm(self.prior_H.row_inv.to(self.H.dtype), self.H.detach().contiguous())
+        """(row + jitter I)^-1 H.  The RBF Gram matrix is extremely ill-conditioned (kappa ~ 1e10 with the
+        1e-5 jitter), so the two triangular solves run in float64 on the prior's cached Cholesky inverse."""
+        prior = self.prior_H
+        if getattr(prior, '_W64', None) is None:
+            prior._W64, _ = ops.chol_inv(prior._row_j.double().contiguous())
+        W = prior._W64
+        rhs = ops.gemm(W, self.H.detach().double().contiguous(), flags=ops.GEMM_A_LOWER)
+        return ops.gemm(W, rhs, ta=True, flags=ops.GEMM_A_UPPER).to(self.H.dtype)
 
     def expectation_conditional_matrix_variate_dist(self, x_star):
         cross = self.row_covar_kernel(x_star, self.x).evaluate()            # (N*, N)

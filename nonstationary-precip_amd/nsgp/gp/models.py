@@ -175,6 +175,31 @@ class DeepGP(GP):
     def forward(self, x):
         raise NotImplementedError
 
+    def __call__(self, *args, **kwargs):
+        """Kzz, its Cholesky factor and inverse depend on parameters only: do them for EVERY layer of
+        the model up front in one batched potrf/trtri chain (one serial dependency chain per step
+        instead of one per layer), then run the user's forward."""
+        from ..svgp import whiten
+        strategies = [s for s in self.variational_strategy.sub_variational_strategies
+                      if hasattr(s, 'whiten_group')]
+        shared = False
+        if len(strategies) > 1 and len({s.inducing_points.shape[-2] for s in strategies}) == 1 \
+                and args and torch.is_tensor(args[0]) and args[0].is_cuda:
+            for s in strategies:
+                s._maybe_init()
+            groups = [s.whiten_group() for s in strategies]
+            Ws, _info = whiten(groups, settings.variational_cholesky_jitter.value(args[0].dtype),
+                               settings.chol_bwd_f64.on())
+            for s, W in zip(strategies, Ws):
+                s._W64_shared = W
+            shared = True
+        try:
+            return super().__call__(*args, **kwargs)
+        finally:
+            if shared:
+                for s in strategies:
+                    s._W64_shared = None
+
 
 class DeepLikelihood(GaussianLikelihood):
     pass

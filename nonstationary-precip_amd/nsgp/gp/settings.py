@@ -107,3 +107,9 @@ class eps_provider(_value_context):
     """None -> torch.randn on the input's device (what Normal.rsample does in the reference);
     otherwise a callable (shape, dtype, device, call_index) -> eps, e.g. nsgp.dist.PhiloxEps."""
     _global_value = None
+
+
+class chol_bwd_f64(_feature_flag):
+    """Adjoint of the Kzz Cholesky inverse in float64 (on, default: what autograd does in the reference,
+    where the factor and the solve are float64) or in float32 (off: 3x less MFMA time)."""
+    _state = True

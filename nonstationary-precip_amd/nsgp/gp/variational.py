@@ -9,7 +9,7 @@ inverse once per call in float64, then MFMA GEMMs -- no per-sample recomputation
 import torch
 
 from .. import ops
-from ..svgp import svgp_marginal, VAR_JITTER
+from ..svgp import svgp_marginal, whiten, VAR_JITTER
 from . import settings
 from .distributions import MultivariateNormal
 from .kernels import RBFKernel, ScaleKernel
@@ -66,9 +66,11 @@ class _VariationalStrategy(Module):
         return self._variational_distribution()
 
     def _maybe_init(self):
-        if self.training and not bool(self.variational_params_initialized.item()):
-            self._variational_distribution.initialize_variational_distribution()
-            self.variational_params_initialized.fill_(1)
+        if self.training and not getattr(self, '_init_done', False):
+            if not bool(self.variational_params_initialized.item()):        # one host sync, first call only
+                self._variational_distribution.initialize_variational_distribution()
+                self.variational_params_initialized.fill_(1)
+            self._init_done = True
 
 
 class VariationalStrategy(_VariationalStrategy):
@@ -92,12 +94,19 @@ class VariationalStrategy(_VariationalStrategy):
         os_ = kern.outputscale.reshape(-1).expand(b)
         return Z, ls, os_, m, Lq
 
+    def whiten_group(self):
+        """(Z, ls, os) of this layer's GPs for the batched Kzz -> Cholesky -> inverse chain."""
+        Z, ls, os_, _, _ = self._flat_params()
+        return Z, ls.contiguous(), os_.contiguous()
+
     def marginals(self, x_flat):
         """x_flat:(n,D) shared by all output GPs -> mean (b,n) incl. the prior mean, var (b,n)."""
         self._maybe_init()
         Z, ls, os_, m, Lq = self._flat_params()
         jitter = settings.variational_cholesky_jitter.value(x_flat.dtype)
-        mean, var, _info = svgp_marginal(x_flat, Z, ls.contiguous(), os_.contiguous(), m, Lq, jitter=jitter)
+        W64 = getattr(self, '_W64_shared', None)         # set by DeepGP.__call__ (one chain for all layers)
+        mean, var, _info = svgp_marginal(x_flat, Z, ls.contiguous(), os_.contiguous(), m, Lq, jitter=jitter,
+                                         chol_bwd_f64=settings.chol_bwd_f64.on(), W64=W64)
         b = Z.shape[0]
         xin = x_flat if b == 1 and self.inducing_points.dim() == 2 else x_flat.unsqueeze(0).expand(b, *x_flat.shape)
         prior_mean = self.model.mean_module(xin).reshape(b, -1)

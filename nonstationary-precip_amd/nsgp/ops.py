@@ -227,7 +227,7 @@ _gemm_timer = None
 
 
 def set_gemm_timer(timer):
-    """bench.py hook: `timer(fn, flops)` must call fn() (the launch) and may bracket it with HIP events.
+    """bench.py hook: `timer(fn, flops, dtype)` must call fn() (the launch) and may bracket it with HIP events.
     flops = algorithmic 2*M*N*K per batch element, halved for a triangular operand / lower-only output."""
     global _gemm_timer
     _gemm_timer = timer
@@ -258,7 +258,7 @@ def gemm(A, B, ta=False, tb=False, alpha=1.0, beta=0.0, out=None, flags=0):
         if tuple(out.shape) != shape or not out.is_contiguous():
             raise BackendError(f'gemm: out must be contiguous {shape}, got {tuple(out.shape)}')
     lib = _lib.load()
-    wsb = 0 if (flags & GEMM_NO_SPLITK) else lib.nsgp_gemm_workspace(M, N, K, nb, 1, ref.element_size())
+    wsb = 0 if (flags & GEMM_NO_SPLITK) else lib.nsgp_gemm_workspace(M, N, K, nb, 1, ref.element_size(), int(flags))
     ws = _ws(wsb, ref.device) if wsb else None
     def launch():
         _lib.call(f'nsgp_gemm_{_sfx(ref)}', M, N, K, float(alpha), _p(A), sam, sak, sba, 0, _p(B), sbk, sbn, sbb, 0,
@@ -266,7 +266,7 @@ def gemm(A, B, ta=False, tb=False, alpha=1.0, beta=0.0, out=None, flags=0):
                   _stream())
     if _gemm_timer is not None:
         tri = flags & (GEMM_A_LOWER | GEMM_A_UPPER | GEMM_B_LOWER | GEMM_B_UPPER | GEMM_C_LOWER)
-        _gemm_timer(launch, 2.0 * M * N * K * nb * (0.5 if tri else 1.0))
+        _gemm_timer(launch, 2.0 * M * N * K * nb * (0.5 if tri else 1.0), ref.dtype)
     else:
         launch()
     return out

@@ -1,4 +1,4 @@
-"""Whitened SVGP layer marginals as ONE autograd node with a hand-derived backward.
+"""Whitened SVGP layer marginals as fused autograd nodes with hand-derived backward passes.
 
 What gpytorch's VariationalStrategy.forward does per layer (driven by
 models/dgps.py:48-51 through DeepGPLayer.__call__):
@@ -7,12 +7,13 @@ models/dgps.py:48-51 through DeepGPLayer.__call__):
     mean = A^T m (+ mu(x), added by the caller) ; var = kxx + 1e-4 + colsum(A o ((Lq Lq^T - I) A))
 
 MI355X formulation (same math, no per-sample redundancy, everything on the matrix cores):
-    W   = chol(Kzz)^-1              float64 potrf + trtri, once per layer per step (M^3 work)
+    W   = chol(Kzz)^-1              float64 potrf + trtri  -- parameter-only work, done ONCE per step
+                                    for every layer of the model in one batched chain (WhitenFn)
     A   = W Kzx                     f32 MFMA GEMM, lower-triangular W skips half the K-tiles
     C   = Lq^T A                    f32 MFMA GEMM, upper-triangular operand
     var = base + colsum(C o C) - colsum(A o A)
-The backward is 4 more (M x M x n) GEMMs + the M^3 Cholesky adjoint; every identity is checked
-against torch autograd of the oracle in tests/test_gpu_svgp.py.
+The backward is 4 more (M x M x n) GEMMs per layer (SVGPLayerFn) + one batched M^3 Cholesky adjoint
+(WhitenFn); every identity is checked against torch autograd of the oracle in tests/test_gpu_svgp.py.
 """
 import torch
 
@@ -22,65 +23,119 @@ from .ops import GEMM_A_LOWER, GEMM_A_UPPER, GEMM_B_LOWER, GEMM_B_UPPER, GEMM_C_
 VAR_JITTER = 1e-4          # data_data_covar.add_jitter(1e-4) in VariationalStrategy.forward
 
 
-class SVGPLayerFn(torch.autograd.Function):
-    """(x, Z, ls, os, m, Lq) -> (mean_without_prior_mean:(b,n), var:(b,n), info:(b,))
+class WhitenFn(torch.autograd.Function):
+    """W[g] = chol(os_g RBF(Z_g, Z_g; ls_g) + jitter I)^-1 in float64 for a list of GP groups.
 
-    x:(n,D) shared by the b output GPs, or (b,n,D);  Z:(b,M,D)  ls:(b,D)  os:(b,)  m:(b,M)  Lq:(b,M,M)
-    (only the lower triangle of Lq is used, like CholeskyVariationalDistribution.forward).
+    inputs: jitter, chol_bwd_f64, then (Z_i:(b_i,M,D_i), ls_i:(b_i,D_i), os_i:(b_i,)) per group, all with
+    the same M.  Output: W64:(sum b_i, M, M) float64 and info:(sum b_i,).  The Gram matrices are built
+    per group (the input dimension differs between layers), then ONE batched potrf + trtri chain
+    factors them all; the adjoint  Kbar = -1/2 W^T (Phi(B) + Phi(B)^T) W,  B = tril(Wbar) W^T  is three
+    batched MFMA GEMMs.
     """
 
     @staticmethod
-    def forward(ctx, x, Z, ls, os_, m, Lq, jitter, chol_bwd_f64):
-        work = x.dtype
-        Z64, ls64, os64 = Z.double(), ls.double(), os_.double()
-        Kzz = ops.rbf_build(Z64, Z64, ls64, os64, diag_add=jitter)              # (b,M,M) f64
-        L, info = ops.potrf(Kzz, overwrite=True)
+    def forward(ctx, jitter, chol_bwd_f64, *params):
+        groups = [params[i:i + 3] for i in range(0, len(params), 3)]
+        Ks, z64 = [], []
+        for Z, ls, os_ in groups:
+            Zd, lsd, osd = Z.double(), ls.double(), os_.double()
+            z64.append((Zd, lsd, osd))
+            Ks.append(ops.rbf_build(Zd, Zd, lsd, osd, diag_add=jitter))
+        K = Ks[0] if len(Ks) == 1 else torch.cat(Ks, dim=0)
+        L, info = ops.potrf(K, overwrite=True)
         W64 = ops.trtri(L)
-        W = ops.cast(W64, work)
+        ctx.save_for_backward(W64, *[t for g in z64 for t in g])
+        ctx.sizes = [g[0].shape[0] for g in groups]
+        ctx.dtypes = [g[0].dtype for g in groups]
+        ctx.chol_bwd_f64 = chol_bwd_f64
+        ctx.mark_non_differentiable(info)
+        outs, off = [], 0
+        for b in ctx.sizes:                      # one output per group (views of the batched result)
+            outs.append(W64[off:off + b])
+            off += b
+        return (*outs, info)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        W64, *flat = ctx.saved_tensors
+        parts = []
+        for gi, b in enumerate(ctx.sizes):
+            g = gouts[gi]
+            parts.append(g if g is not None else torch.zeros((b, *W64.shape[1:]), dtype=W64.dtype, device=W64.device))
+        Wbar = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
+        if ctx.chol_bwd_f64:
+            Wb, Wc = Wbar.contiguous(), W64
+        else:
+            Wb, Wc = ops.cast(Wbar.contiguous(), torch.float32), ops.cast(W64, torch.float32)
+        Bm = ops.gemm(Wb, Wc, tb=True, flags=GEMM_A_LOWER | GEMM_B_UPPER)
+        S = ops.chol_bwd_phi_sym(Bm)
+        T = ops.gemm(S, Wc, flags=GEMM_B_LOWER)
+        Kbar = ops.gemm(Wc, T, ta=True, alpha=-0.5, flags=GEMM_A_UPPER)
+        grads, off = [None, None], 0
+        for gi, b in enumerate(ctx.sizes):
+            Zd, lsd, osd = flat[3 * gi:3 * gi + 3]
+            Kb = Kbar[off:off + b]
+            off += b
+            if Kb.dtype != torch.float64:
+                Zk, lsk, osk = Zd.float(), lsd.float(), osd.float()
+            else:
+                Zk, lsk, osk = Zd, lsd, osd
+            gZa, gZb, gls, gos = ops.rbf_build_bwd(Zk, Zk, lsk, osk, Kb.contiguous())
+            dt = ctx.dtypes[gi]
+            grads += [(gZa + gZb).to(dt), gls.to(dt), gos.to(dt)]
+        return tuple(grads)
+
+
+def whiten(groups, jitter=1e-4, chol_bwd_f64=True):
+    """groups: list of (Z:(b,M,D), ls:(b,D), os:(b,)).  Returns (list of W64:(b,M,M) per group, info)."""
+    flat = [t for g in groups for t in g]
+    *Ws, info = WhitenFn.apply(float(jitter), bool(chol_bwd_f64), *flat)
+    return list(Ws), info
+
+
+class SVGPLayerFn(torch.autograd.Function):
+    """(x, Z, ls, os, m, Lq, W64) -> (mean_without_prior_mean:(b,n), var:(b,n))
+
+    x:(n,D) shared by the b output GPs, or (b,n,D);  Z:(b,M,D)  ls:(b,D)  os:(b,)  m:(b,M)  Lq:(b,M,M)
+    (only the lower triangle of Lq is used, like CholeskyVariationalDistribution.forward);
+    W64:(b,M,M) = chol(Kzz)^-1 from WhitenFn (float64).  The dependence of Kzz on (Z, ls, os) flows
+    through W64's gradient; this node differentiates the Kzx path.
+    """
+
+    @staticmethod
+    def forward(ctx, x, Z, ls, os_, m, Lq, W64):
+        W = ops.cast(W64, x.dtype)
         Kzx = ops.rbf_build(Z, x, ls, os_)                                       # (b,M,n)
         A = ops.gemm(W, Kzx, flags=GEMM_A_LOWER)
         C = ops.gemm(Lq, A, ta=True, flags=GEMM_A_UPPER)
         mean, var = ops.svgp_colstats(A, C, m, os_ + VAR_JITTER)
-        ctx.save_for_backward(x, Z, ls, os_, m, Lq, W64, W, Kzx, A, C)
-        ctx.chol_bwd_f64 = chol_bwd_f64
-        ctx.mark_non_differentiable(info)
-        return mean, var, info
+        ctx.save_for_backward(x, Z, ls, os_, m, Lq, W, Kzx, A, C)
+        ctx.w_dtype = W64.dtype
+        return mean, var
 
     @staticmethod
-    def backward(ctx, gmean, gvar, _ginfo):
-        x, Z, ls, os_, m, Lq, W64, W, Kzx, A, C = ctx.saved_tensors
+    def backward(ctx, gmean, gvar):
+        x, Z, ls, os_, m, Lq, W, Kzx, A, C = ctx.saved_tensors
         gmean, gvar = gmean.contiguous(), gvar.contiguous()
         Abar, C2, mbar = ops.svgp_colstats_bwd(A, C, m, gmean, gvar)
         ops.gemm(Lq, C2, flags=GEMM_A_LOWER, beta=1.0, out=Abar)                # Abar += Lq C2
         Lqbar = ops.gemm(A, C2, tb=True, flags=GEMM_C_LOWER)                     # tril(A C2^T)
         Kzxbar = ops.gemm(W, Abar, ta=True, flags=GEMM_A_UPPER)                  # W^T Abar
         Wbar = ops.gemm(Abar, Kzx, tb=True, flags=GEMM_C_LOWER)                  # tril(Abar Kzx^T)
-        # Cholesky-inverse adjoint:  Kzz_bar = -1/2 W^T (Phi(B) + Phi(B)^T) W,  B = tril(Wbar) W^T
-        if ctx.chol_bwd_f64 or W.dtype == torch.float64:
-            Wb, Wc = ops.cast(Wbar, torch.float64), W64
-        else:
-            Wb, Wc = Wbar, W
-        Bm = ops.gemm(Wb, Wc, tb=True, flags=GEMM_A_LOWER | GEMM_B_UPPER)
-        S = ops.chol_bwd_phi_sym(Bm)
-        T = ops.gemm(S, Wc, flags=GEMM_B_LOWER)
-        Kzzbar = ops.gemm(Wc, T, ta=True, alpha=-0.5, flags=GEMM_A_UPPER)
         need_x = ctx.needs_input_grad[0]
-        gZ1, gx, gls1, gos1 = ops.rbf_build_bwd(Z, x, ls, os_, Kzxbar, need_x1=True, need_x2=need_x)
-        if Kzzbar.dtype == torch.float64:
-            Zk, lsk, osk = Z.double(), ls.double(), os_.double()
-        else:
-            Zk, lsk, osk = Z, ls, os_
-        gZa, gZb, gls2, gos2 = ops.rbf_build_bwd(Zk, Zk, lsk, osk, Kzzbar)
-        work = x.dtype
-        Zbar = gZ1 + (gZa + gZb).to(work)
-        lsbar = gls1 + gls2.to(work)
-        osbar = gos1 + gos2.to(work) + gvar.sum(-1)
+        gZ, gx, gls, gos = ops.rbf_build_bwd(Z, x, ls, os_, Kzxbar, need_x1=True, need_x2=need_x)
+        gos = gos + gvar.sum(-1)
         if need_x and x.dim() == 2:
             gx = gx.sum(0)
-        return (gx if need_x else None, Zbar, lsbar.reshape(ls.shape), osbar.reshape(os_.shape), mbar, Lqbar,
-                None, None)
+        return (gx if need_x else None, gZ, gls.reshape(ls.shape), gos.reshape(os_.shape), mbar, Lqbar,
+                ops.cast(Wbar, ctx.w_dtype))
 
 
-def svgp_marginal(x, Z, ls, os_, m, Lq, jitter=1e-4, chol_bwd_f64=True):
-    """mean (without the prior mean function) and variance of q(f) at x for b whitened SVGPs."""
-    return SVGPLayerFn.apply(x, Z, ls, os_, m, Lq, float(jitter), bool(chol_bwd_f64))
+def svgp_marginal(x, Z, ls, os_, m, Lq, jitter=1e-4, chol_bwd_f64=True, W64=None):
+    """mean (without the prior mean function) and variance of q(f) at x for b whitened SVGPs.
+    Returns (mean, var, info); pass W64 (from `whiten`) to share one factorisation chain across layers."""
+    info = None
+    if W64 is None:
+        (W64,), info = whiten([(Z, ls, os_)], jitter, chol_bwd_f64)
+    mean, var = SVGPLayerFn.apply(x, Z, ls, os_, m, Lq, W64)
+    return mean, var, info

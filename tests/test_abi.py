@@ -31,8 +31,8 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(raw, name), name
     # host-only size queries are safe without a GPU
     assert lib.nsgp_potrf_workspace(1024, 3, 8) == 3 * 16 * 64 * 64 * 8
-    assert lib.nsgp_gemm_workspace(1024, 40960, 1024, 1, 1, 4) == 0
-    assert lib.nsgp_gemm_workspace(1024, 1024, 40960, 1, 1, 4) > 0
+    assert lib.nsgp_gemm_workspace(1024, 40960, 1024, 1, 1, 4, 0) == 0
+    assert lib.nsgp_gemm_workspace(1024, 1024, 40960, 1, 1, 4, 16) > 0
 
 
 def test_no_signature_in_the_header_uses_torch_or_cxx_types():

@@ -91,8 +91,9 @@ def _build(num_layers, D, M, seed):
     return model, settings
 
 
+@pytest.mark.parametrize('chol_bwd_f64', [True, False])
 @pytest.mark.parametrize('num_layers,D,M,B,S', [(1, 3, 40, 315, 3), (2, 2, 64, 128, 4), (1, 2, 130, 200, 10)])
-def test_dsvi_elbo_and_gradients_match_oracle(num_layers, D, M, B, S):
+def test_dsvi_elbo_and_gradients_match_oracle(num_layers, D, M, B, S, chol_bwd_f64):
     _need_gpu()
     from oracle import svgp
     from nsgp.gp.mlls import DeepApproximateMLL, VariationalELBO
@@ -104,24 +105,28 @@ def test_dsvi_elbo_and_gradients_match_oracle(num_layers, D, M, B, S):
     N = 5000
     mll = DeepApproximateMLL(VariationalELBO(model.likelihood, model, N))
     model.train()
-    with settings.num_likelihood_samples(S), settings.eps_provider(_FixedEps(eps)):
+    with settings.num_likelihood_samples(S), settings.eps_provider(_FixedEps(eps)), \
+            settings.chol_bwd_f64(chol_bwd_f64):
         out = model(x.cuda())
         elbo = mll(out, y.cuda())
-    assert out.mean.shape == (S, B) and out.variance.shape == (S, B)
-    elbo.backward()
+        assert out.mean.shape == (S, B) and out.variance.shape == (S, B)
+        elbo.backward()
 
     hidden, last, noise, leaves = _oracle_layers(model)
     ref = svgp.dsvi_elbo(x.double(), y.double(), hidden, last, num_layers, [e.double() for e in eps], S, noise, N)
     ref.backward()
     # float32 pipeline vs float64 oracle: ELBO to 2e-4 relative
     assert abs(float(elbo) - float(ref)) < 2e-4 * abs(float(ref)) + 1e-5
+    errs = {}
     for name, p in _model_params(model).items():
         got, want = p.grad.detach().cpu().double(), leaves[name].grad
         if name.endswith('Lq'):
             want = torch.tril(want)
         scale = float(want.abs().max()) + 1e-12
         err = float((got - want).abs().max()) / scale
-        assert err < 2e-2, (name, err)                       # per-parameter max-norm relative error
+        errs[name] = err
+        assert err < 2e-2, (name, err, chol_bwd_f64)         # per-parameter max-norm relative error
+    print('max grad rel err', chol_bwd_f64, max(errs.values()), max(errs, key=errs.get))
 
 
 def test_predict_matches_oracle_and_full_covariance_is_consistent():
