@@ -15,6 +15,7 @@
 // buffers, one barrier per K-tile.  Triangular operands skip whole K-tiles and are masked in the
 // diagonal tiles; small outputs with a long inner dimension are split along K into slabs that a
 // second kernel sums in a fixed order (deterministic).
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -110,30 +111,57 @@ __device__ __forceinline__ Frag4<T> load_operand4(const T* base, int64_t sr, int
 }
 
 // MODE_A / MODE_B: 0 = operand contiguous along k, 1 = contiguous along m (n).
-template <typename T, int BM, int BN, int MODE_A, int MODE_B>
+template <typename T, int BM, int BN, int BK, int MODE_A, int MODE_B>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g, T alpha, const T* __restrict__ A,
                                                    const T* __restrict__ B, T beta, T* __restrict__ C,
                                                    T* __restrict__ slabs) {
     using MF = Mfma<T>;
-    constexpr int BK = 16;
     constexpr int MT = MF::MT, KS = MF::KS, NKK = BK / KS;
+    constexpr int KCH = NKK < 8 ? NKK : 8;                      // k-steps whose fragments are prefetched together
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int TM = WM / MT, TN = WN / MT;
-    constexpr int LDA = BM + MF::PAD, LDB = BN + MF::PAD;
+    constexpr int PADA = (MODE_A == 0 && sizeof(T) == 4) ? 1 : MF::PAD;
+    constexpr int PADB = (MODE_B == 0 && sizeof(T) == 4) ? 1 : MF::PAD;
+    constexpr int LDA = BM + PADA, LDB = BN + PADB;
     constexpr int PA = BM * BK / 1024, PB = BN * BK / 1024;     // 4-element fragments per thread
     constexpr int TPRA = BM / 4, TPRB = BN / 4;                 // threads per k-row in mode 1
-    __shared__ __attribute__((aligned(32))) T As[2][BK * LDA];
-    __shared__ __attribute__((aligned(32))) T Bs[2][BK * LDB];
+    constexpr int TPK = BK / 4;                                 // threads per row in mode 0 (full BK bytes)
+    // all LDS in ONE dynamic region (the 128x128x32 f32 tile needs 66 KB > the 64 KB static limit)
+    extern __shared__ __attribute__((aligned(32))) unsigned char gemm_smem[];
+    T (*As)[BK * LDA] = reinterpret_cast<T (*)[BK * LDA]>(gemm_smem);
+    T (*Bs)[BK * LDB] = reinterpret_cast<T (*)[BK * LDB]>(gemm_smem + 2 * BK * LDA * sizeof(T));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
     // tile id -> (bm, bn): bn fastest, so the workgroups in flight share one A row panel (L2 resident) and
-    // stream disjoint B column panels.  Triangular operands make the work per tile uneven: rows with the
-    // longest K range are issued first (longest-processing-time order), which shortens the tail.
-    // (Measured on MI355X, M=1024, N=40960, K=1024 lower-triangular A: 524 us vs 577 us natural order vs
-    //  700-850 us for XCD-chunked orders, which put whole tile rows -- unequal work -- on one XCD.)
+    // stream disjoint B column panels.  Triangular operands / outputs make the work per tile uneven:
+    //  * rows with the longest K range are issued first (longest-processing-time order);
+    //  * the column index is rotated by the row index.  Workgroups are dealt round-robin to the 8 XCDs
+    //    (id % 8), so without the rotation an XCD owns fixed tile COLUMNS -- with a lower-triangular
+    //    output and 8 tile columns XCD 0 gets 8 active tiles per slice and XCD 7 one (measured: the
+    //    lower-only M=N=1024, K=40960 product took 879 us, the FULL product 780 us).
     const int64_t tid_lin = blockIdx.x;
-    int64_t bn = tid_lin % g.tiles_n, bm = tid_lin / g.tiles_n;
+    int64_t bm, bn;
+    if (g.flags & NSGP_GEMM_C_LOWER) {
+        // compact enumeration of the ACTIVE tiles only (n0 <= m0 + BM - 1): launching the strictly-upper
+        // tiles as no-op workgroups perturbs the dispatcher's CU placement (measured: lower-only product
+        // no faster than the full one, CUs ~58 % busy).  Rows 0..T-1 form a triangle, the rest are full.
+        const int64_t TT = g.tiles_m < g.tiles_n ? g.tiles_m : g.tiles_n;
+        const int64_t tri = TT * (TT + 1) / 2;
+        if (tid_lin < tri) {
+            int64_t r = (int64_t)((sqrtf(8.0f * (float)tid_lin + 1.0f) - 1.0f) * 0.5f);
+            while (r * (r + 1) / 2 > tid_lin) --r;
+            while ((r + 1) * (r + 2) / 2 <= tid_lin) ++r;
+            bm = r; bn = tid_lin - r * (r + 1) / 2;
+        } else {
+            const int64_t q = tid_lin - tri;
+            bm = TT + q / g.tiles_n; bn = q % g.tiles_n;
+        }
+    } else {
+        const int64_t brow = tid_lin / g.tiles_n;
+        // (j - row) mod tiles_n: spreads a triangular B operand's heavy columns over the XCDs (id % 8)
+        bm = brow; bn = (tid_lin % g.tiles_n + g.tiles_n - brow % g.tiles_n) % g.tiles_n;
+    }
     if (g.flags & NSGP_GEMM_A_LOWER) bm = g.tiles_m - 1 - bm;          // large m = long K range
     if (g.flags & NSGP_GEMM_B_UPPER) bn = g.tiles_n - 1 - bn;          // large n = long K range
     const int64_t z = blockIdx.y;
@@ -171,12 +199,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g, T alpha, const
     int ar[PA], ak[PA], br[PB], bk[PB];
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
-        if (MODE_A == 0) { ar[p] = p * 64 + (tid >> 2); ak[p] = (tid & 3) * 4; }
+        if (MODE_A == 0) { ar[p] = p * (256 / TPK) + tid / TPK; ak[p] = (tid % TPK) * 4; }
         else { ar[p] = (tid % TPRA) * 4; ak[p] = p * (256 / TPRA) + tid / TPRA; }
     }
 #pragma unroll
     for (int p = 0; p < PB; ++p) {
-        if (MODE_B == 0) { br[p] = p * 64 + (tid >> 2); bk[p] = (tid & 3) * 4; }
+        if (MODE_B == 0) { br[p] = p * (256 / TPK) + tid / TPK; bk[p] = (tid % TPK) * 4; }
         else { br[p] = (tid % TPRB) * 4; bk[p] = p * (256 / TPRB) + tid / TPRB; }
     }
     // fast path: every 16-byte fragment of the tile is in bounds, aligned and unmasked
@@ -248,22 +276,24 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g, T alpha, const
             if (t + 1 < nt) gload(kbeg + (t + 1) * BK);             // next tile -> registers (in flight)
             const T* as = &As[buf][kr * LDA + wm0 + mc];
             const T* bs = &Bs[buf][kr * LDB + wn0 + mc];
-            // all operand fragments of this K-tile first (LDS latency overlaps the MFMA stream) ...
-            T af[NKK][TM], bf[NKK][TN];
+            // operand fragments of KCH k-steps first (LDS latency overlaps the MFMA stream), then the MFMAs
 #pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) {
+            for (int kc = 0; kc < NKK; kc += KCH) {
+                T af[KCH][TM], bf[KCH][TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[kk][i] = as[kk * KS * LDA + i * MT];
+                for (int kk = 0; kk < KCH; ++kk) {
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bf[kk][j] = bs[kk * KS * LDB + j * MT];
+                    for (int i = 0; i < TM; ++i) af[kk][i] = as[(kc + kk) * KS * LDA + i * MT];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bf[kk][j] = bs[(kc + kk) * KS * LDB + j * MT];
+                }
+#pragma unroll
+                for (int kk = 0; kk < KCH; ++kk)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(af[kk][i], bf[kk][j], acc[i][j]);
             }
-            // ... then the MFMAs
-#pragma unroll
-            for (int kk = 0; kk < NKK; ++kk)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(af[kk][i], bf[kk][j], acc[i][j]);
             if (t + 1 < nt) sstore(buf ^ 1);
             __syncthreads();
         }
@@ -330,6 +360,10 @@ static inline int64_t active_tiles(int64_t M, int64_t N, int64_t bm, int flags) 
     return cnt;
 }
 
+// Tile size and K-split.  Resident workgroups ("slots") = 256 CUs x blocks/CU for the kernel variant
+// (2 for the 128x128 f32 tile, 6 / 3 for the 64x64 f32 / f64 tiles); the number of rounds the grid needs
+// is ceil(active_blocks / slots), so the K-split is chosen to minimise rounds x K-tiles per block plus
+// the slab traffic of the split (measured: 792 active blocks on 512 slots ran 905 us, CUs 55 % busy).
 template <typename T> Plan make_plan(int64_t M, int64_t N, int64_t K, int64_t nb, int flags) {
     Plan p;
     const bool can_split = !(flags & NSGP_GEMM_NO_SPLITK) && K >= 512;
@@ -341,14 +375,20 @@ template <typename T> Plan make_plan(int64_t M, int64_t N, int64_t K, int64_t nb
     p.big = sizeof(T) == 4 && tiles_big * maxks >= 256;
     const int64_t bm = p.big ? 128 : 64;
     const int64_t tiles = active_tiles(M, N, bm, flags) * nb;
-    int64_t ks = 1;
-    const int64_t target = p.big ? 768 : 1024;        // ~3 (4) resident workgroups per CU
-    if (tiles < target) {
-        ks = cdiv64(target, tiles);
-        if (ks > maxks) ks = maxks;
+    const int64_t slots = 256 * (p.big ? 2 : (sizeof(T) == 4 ? 6 : 3));
+    const int64_t ktiles = cdiv64(K, 16);
+    int64_t best_ks = 1;
+    double best_cost = 1e300;
+    for (int64_t ks = 1; ks <= maxks; ++ks) {
+        const int64_t rounds = cdiv64(tiles * ks, slots);
+        // K-tiles of MFMA work per round + per-block fixed cost (prologue/epilogue ~ 6 K-tiles) + the
+        // split's slab write/read (in K-tile units: one 128x128 fp32 slab ~ 2 K-tiles of time)
+        const double cost = (double)rounds * ((double)cdiv64(ktiles, ks) + 6.0) + (ks > 1 ? 2.0 * ks / 4.0 : 0.0);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best_ks = ks; }
     }
-    p.kper = cdiv64(cdiv64(K, ks), 16) * 16;
-    if (p.kper < 16) p.kper = 16;
+    { const char* e = getenv("NSGP_GEMM_KSPLIT"); if (e && can_split) best_ks = atoi(e); }
+    p.kper = cdiv64(cdiv64(K, best_ks), 32) * 32;
+    if (p.kper < 32) p.kper = 32;
     p.ksplit = cdiv64(K, p.kper);
     if (p.ksplit < 1) p.ksplit = 1;
     return p;
@@ -392,9 +432,32 @@ int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam,
     g.tiles_m = cdiv64(M, bmn);
     g.tiles_n = cdiv64(N, bmn);
     if (g.tiles_m * g.tiles_n > 2147483647LL || nb * g.ksplit > 65535) return -24;
-    dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)(nb * g.ksplit), 1);
+    const int64_t ngrid = (flags & NSGP_GEMM_C_LOWER) ? active_tiles(M, N, bmn, flags) : g.tiles_m * g.tiles_n;
+    if ((flags & NSGP_GEMM_C_LOWER) && g.ksplit == 1 && beta == T(0)) {
+        // the strictly-upper tiles are not launched: keep the "strict upper triangle is zero" contract
+        // (the split-K reduce kernel writes those zeros itself)
+        for (int64_t i1 = 0; i1 < nb1; ++i1)
+            for (int64_t i2 = 0; i2 < nb2; ++i2) {
+                hipError_t e = hipMemset2DAsync(C + i1 * sc1 + i2 * sc2, (size_t)ldc * sizeof(T), 0,
+                                                (size_t)N * sizeof(T), (size_t)M, st);
+                if (e != hipSuccess) return (int)e;
+            }
+    }
+    dim3 grid((unsigned)ngrid, (unsigned)(nb * g.ksplit), 1);
 #define NSGP_LAUNCH(BMN, MA, MB)                                                                          \
-    hipLaunchKernelGGL((gemm_kernel<T, BMN, BMN, MA, MB>), grid, dim3(256), 0, st, g, alpha, A, B, beta, C, slabs)
+    do {                                                                                                  \
+        constexpr int BKc = (BMN == 128 ? 32 : 16);                                                       \
+        constexpr int pa = (MA == 0 && sizeof(T) == 4) ? 1 : Mfma<T>::PAD;                                \
+        constexpr int pb = (MB == 0 && sizeof(T) == 4) ? 1 : Mfma<T>::PAD;                                \
+        constexpr size_t lds = 2 * BKc * ((BMN + pa) + (BMN + pb)) * sizeof(T);                           \
+        auto kern = gemm_kernel<T, BMN, BMN, BKc, MA, MB>;                                                \
+        static bool attr_done = false;                                                                    \
+        if (!attr_done && lds > 65536) {                                                                  \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        }                                                                                                 \
+        attr_done = true;                                                                                 \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g, alpha, A, B, beta, C, slabs);               \
+    } while (0)
 #define NSGP_LAUNCH_MODES(BMN)                                                 \
     do {                                                                       \
         if (g.modeA == 0 && g.modeB == 0) NSGP_LAUNCH(BMN, 0, 0);              \

@@ -16,9 +16,26 @@ dt = torch.float32
 g = torch.Generator().manual_seed(0)
 W = torch.tril(torch.randn(M, M, generator=g)).cuda()
 Lq = torch.tril(torch.randn(M, M, generator=g)).cuda()
-K = torch.randn(M, n, generator=g).cuda()
-A = torch.randn(M, n, generator=g).cuda()
+PAD = int(os.environ.get('PAD', 0))
+
+
+def padded(t):
+    if not PAD:
+        return t.cuda()
+    buf = torch.empty(t.shape[0], t.shape[1] + PAD, device='cuda')
+    v = buf[:, :t.shape[1]]
+    v.copy_(t)
+    return v
+
+
+K = padded(torch.randn(M, n, generator=g))
+A = padded(torch.randn(M, n, generator=g))
+W = padded(W.cpu())
+Lq = padded(Lq.cpu())
 out = torch.empty(M, n, device='cuda')
+Bt = torch.randn(n, M, generator=g).cuda()
+At = torch.randn(n, M, generator=g).cuda()
+print('PAD', PAD, 'strides', K.stride(), W.stride())
 
 cases = [
     ('A=W K      NN  A_LOWER', lambda: ops.gemm(W, K, flags=ops.GEMM_A_LOWER), M * M * n),
@@ -27,6 +44,13 @@ cases = [
     ('Lqb=A C2^T NT  C_LOWER', lambda: ops.gemm(A, K, tb=True, flags=ops.GEMM_C_LOWER), M * M * n),
     ('Kb=W^T Ab  TN  A_UPPER', lambda: ops.gemm(W, A, ta=True, flags=ops.GEMM_A_UPPER), M * M * n),
     ('plain NN   full       ', lambda: ops.gemm(W, K), 2 * M * M * n),
+    ('NT wide  W * Bt^T full', lambda: ops.gemm(W, Bt, tb=True), 2 * M * M * n),
+    ('TT? no: TN wide full  ', lambda: ops.gemm(W, K, ta=True), 2 * M * M * n),
+    ('NT long-K full nosplit', lambda: ops.gemm(A, K, tb=True, flags=ops.GEMM_NO_SPLITK), 2 * M * M * n),
+    ('NT long-K full split  ', lambda: ops.gemm(A, K, tb=True), 2 * M * M * n),
+    ('TN long-K full (k-maj)', lambda: ops.gemm(At, Bt, ta=True), 2 * M * M * n),
+    ('TN long-K C_LOWER kmaj', lambda: ops.gemm(At, Bt, ta=True, flags=ops.GEMM_C_LOWER), M * M * n),
+    ('transpose M x n -> n x M', lambda: A.t().contiguous(), 0),
 ]
 only = os.environ.get('ONLY')
 for name, fn, flops in cases:
