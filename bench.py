@@ -78,7 +78,7 @@ def build(device, dp_world):
     torch.manual_seed(SEED)
     model = dgps.DeepGP(1, (N_DATA, 3), num_inducing=M_INDUCING).to(device)
     mll = DeepApproximateMLL(VariationalELBO(model.likelihood, model, N_DATA))
-    opt = FusedAdam(model.parameters(), lr=0.01)
+    opt = FusedAdam(model.parameters(), lr=0.01, capturable=True)
     return model, mll, opt
 
 
@@ -162,6 +162,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly (no hipGraph replay)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -169,10 +170,16 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the nsgp HIP backend has no CPU fallback')
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)          # (rehearsals on a 1-GPU box put every rank on cuda:0)
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     if world > 1:
-        dist.init_process_group('nccl', device_id=device)                  # RCCL on ROCm
+        backend = os.environ.get('NSGP_DIST_BACKEND', 'nccl')              # 'nccl' is RCCL on ROCm
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from nsgp import ops
     from nsgp.dist import DataParallel, PhiloxEps, dp_objective, shard_bounds
@@ -190,16 +197,21 @@ def main():
     model, mll, opt = build(device, world)
     dp = DataParallel(opt.bucket)
     dp.broadcast_params()
-    eps = PhiloxEps(SEED, row0=lo)
+    eps = PhiloxEps(SEED, row0=lo, step_dev=opt.step_dev)     # step counter lives on the device
     model.train()
+    # static minibatch buffers: a step always reads these (hipGraph replays need fixed addresses)
+    x_in, y_in = torch.empty_like(xs[0]), torch.empty_like(ys[0])
 
-    def step(k):
-        eps.start_step(k, row0=lo)
+    def fwd_bwd():
+        eps.start_step(0, row0=lo)
         opt.zero_grad()
-        out = model(xs[k % n_batches])
-        loss = -dp_objective(mll, out, ys[k % n_batches], BATCH, world)
+        out = model(x_in)
+        loss = -dp_objective(mll, out, y_in, BATCH, world)
         loss.backward()
-        dp.allreduce_grads()
+        return loss.detach()
+
+    def whole_step():
+        loss = fwd_bwd()
         opt.step()
         return loss
 
@@ -209,6 +221,30 @@ def main():
         torch.cuda.synchronize()
 
     with settings.num_likelihood_samples(S_SAMPLES), settings.eps_provider(eps):
+        use_graph = not args.no_graph
+        if use_graph:
+            from nsgp.graph import GraphedCallable
+            x_in.copy_(xs[0]); y_in.copy_(ys[0])
+            if world == 1:
+                g_step = GraphedCallable(whole_step)                 # forward + ELBO + backward + Adam: one graph
+            else:
+                g_fb = GraphedCallable(fwd_bwd)                      # all-reduce stays an eager RCCL call
+                g_adam = GraphedCallable(opt.step, warmup=1)
+
+        def step(k):
+            x_in.copy_(xs[k % n_batches]); y_in.copy_(ys[k % n_batches])
+            if not use_graph:
+                loss = fwd_bwd()
+                dp.allreduce_grads()
+                opt.step()
+            elif world == 1:
+                loss = g_step()
+            else:
+                loss = g_fb()
+                dp.allreduce_grads()
+                g_adam()
+            return loss
+
         for k in range(args.warmup):
             step(k)
         barrier()
@@ -223,13 +259,16 @@ def main():
             elapsed = float(t.item())
         final_loss = float(loss.item())
 
-        # roofline of the dominant kernel (gemm_kernel<float,128,128>): re-run the same steps with HIP
-        # events around every GEMM launch (kept out of the timed region above)
+        # roofline of the dominant kernel family: re-run the same steps EAGERLY with HIP events around
+        # every GEMM launch (kept out of the timed region above)
         timer = GemmTimer()
         ops.set_gemm_timer(timer)
         nprof = min(args.steps, 5)
         for k in range(nprof):
-            step(args.warmup + args.steps + k)
+            x_in.copy_(xs[k % n_batches]); y_in.copy_(ys[k % n_batches])
+            fwd_bwd()
+            dp.allreduce_grads()
+            opt.step()
         gemm_ms, gemm_flops, gemm_launches = timer.summary(torch.float32)
         g64_ms, g64_flops, g64_launches = timer.summary(torch.float64)
         ops.set_gemm_timer(None)
@@ -247,7 +286,7 @@ def main():
                                    'global minibatch 4096 of synthetic N=1e5 spatio-temporal grid; '
                                    'fwd+ELBO+bwd+Adam', 'M': M_INDUCING, 'S': S_SAMPLES,
                        'global_batch': BATCH, 'N': N_DATA, 'parallelism': f'dp{world}',
-                       'kzz_cholesky_dtype': 'f64'},
+                       'kzz_cholesky_dtype': 'f64', 'hipgraph': bool(use_graph)},
             'final_loss': round(final_loss, 5),
             'roofline': {'bound': 'mfma', 'kernel': 'gemm_kernel<float,128,128,*,*> (all f32 GEMM launches of a step)',
                          'achieved': round(achieved, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',

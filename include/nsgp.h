@@ -234,17 +234,20 @@ int nsgp_cast_f64_to_f32(const double* src, int64_t lds, float* dst, int64_t ldd
 int nsgp_cast_f32_to_f64(const float* src, int64_t lds, double* dst, int64_t ldd, int64_t rows, int64_t cols, void* stream);
 /* counter-based standard normals (Philox4x32-10 + Box-Muller), keyed by
  * (seed, stream_id, global_row, sample, column) so the union over data-parallel ranks equals the
- * single-GPU draw: eps[s, i, c] for rows row0 .. row0+n-1. */
-int nsgp_philox_normal_f32(uint64_t seed, uint64_t stream_id, int64_t row0, int64_t S, int64_t n, int64_t b,
-                           float* eps, void* stream);
-int nsgp_philox_normal_f64(uint64_t seed, uint64_t stream_id, int64_t row0, int64_t S, int64_t n, int64_t b,
-                           double* eps, void* stream);
+ * single-GPU draw: eps[s, i, c] for rows row0 .. row0+n-1.
+ * step_dev (device int64, may be NULL): when given, its value replaces the high 32 bits of stream_id,
+ * so a captured hipGraph draws fresh noise on every replay. */
+int nsgp_philox_normal_f32(uint64_t seed, uint64_t stream_id, const int64_t* step_dev, int64_t row0, int64_t S,
+                           int64_t n, int64_t b, float* eps, void* stream);
+int nsgp_philox_normal_f64(uint64_t seed, uint64_t stream_id, const int64_t* step_dev, int64_t row0, int64_t S,
+                           int64_t n, int64_t b, double* eps, void* stream);
 /* fused Adam over one flat parameter buffer (torch.optim.Adam semantics, lr 0.01 in
- * experiments/deepgp_spatial_bench.py:74-76); step is the 1-based step count; grad_scale
- * multiplies the gradient first (1/world_size after a sum all-reduce). */
+ * experiments/deepgp_spatial_bench.py:74-76); step is the 1-based step count, or step_dev a device
+ * int64 holding it (used instead of `step` when non-NULL: hipGraph replays); grad_scale multiplies the
+ * gradient first. */
 int nsgp_adam_step_f32(float* p, const float* g, float* exp_avg, float* exp_avg_sq, int64_t n,
-                       float lr, float beta1, float beta2, float eps, int64_t step, float grad_scale,
-                       void* stream);
+                       float lr, float beta1, float beta2, float eps, int64_t step, const int64_t* step_dev,
+                       float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -49,8 +49,10 @@ __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uin
 // key = (seed_lo, seed_hi ^ stream_id_hi); words (2q, 2q+1) -> Box-Muller pair q; column c uses
 // normal number (c % 4): pair (c%4)/2, cos for even, sin for odd.
 template <typename T>
-__global__ void philox_normal_kernel(uint64_t seed, uint64_t stream_id, int64_t row0, int64_t S, int64_t n, int64_t b,
-                                     T* __restrict__ eps) {
+__global__ void philox_normal_kernel(uint64_t seed, uint64_t stream_id, const int64_t* __restrict__ step_dev,
+                                     int64_t row0, int64_t S, int64_t n, int64_t b, T* __restrict__ eps) {
+    // a device-side step counter (hipGraph replays freeze host scalars) replaces the high stream word
+    if (step_dev) stream_id = ((uint64_t)step_dev[0] << 32) | (stream_id & 0xFFFFFFFFull);
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t bq = (b + 3) / 4;
     if (idx >= S * n * bq) return;
@@ -78,9 +80,14 @@ __global__ void philox_normal_kernel(uint64_t seed, uint64_t stream_id, int64_t 
 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float bc1,
-                            float bc2_sqrt, float gscale) {
+                            float bc2_sqrt, float gscale, const int64_t* __restrict__ step_dev) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
+    if (step_dev) {                       // bias corrections from the device-side step count (graph replay)
+        const double st = (double)step_dev[0];
+        bc1 = (float)(1.0 - pow((double)b1, st));
+        bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, st));
+    }
     const float gr = g[idx] * gscale;
     const float mi = b1 * m[idx] + (1.0f - b1) * gr;
     const float vi = b2 * v[idx] + (1.0f - b2) * gr * gr;
@@ -112,14 +119,14 @@ int cast_impl(const TS* src, int64_t lds, TD* dst, int64_t ldd, int64_t rows, in
 }
 
 template <typename T>
-int philox_impl(uint64_t seed, uint64_t stream_id, int64_t row0, int64_t S, int64_t n, int64_t b, T* eps,
-                void* stream) {
+int philox_impl(uint64_t seed, uint64_t stream_id, const int64_t* step_dev, int64_t row0, int64_t S, int64_t n,
+                int64_t b, T* eps, void* stream) {
     if (row0 < 0) return -3; if (S < 0 || S >= (1 << 20)) return -4; if (n < 0) return -5;
     if (b < 0 || b > 4 * 4096) return -6; if (!eps) return -7;
     const int64_t tot = S * n * ((b + 3) / 4);
     if (tot == 0) return 0;
     hipLaunchKernelGGL((philox_normal_kernel<T>), dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, (hipStream_t)stream,
-                       seed, stream_id, row0, S, n, b, eps);
+                       seed, stream_id, step_dev, row0, S, n, b, eps);
     return nsgp_launch_status();
 }
 
@@ -146,23 +153,25 @@ int nsgp_cast_f32_to_f64(const float* src, int64_t lds, double* dst, int64_t ldd
                          void* stream) {
     return cast_impl<float, double>(src, lds, dst, ldd, rows, cols, stream);
 }
-int nsgp_philox_normal_f32(uint64_t seed, uint64_t stream_id, int64_t row0, int64_t S, int64_t n, int64_t b,
-                           float* eps, void* stream) {
-    return philox_impl<float>(seed, stream_id, row0, S, n, b, eps, stream);
+int nsgp_philox_normal_f32(uint64_t seed, uint64_t stream_id, const int64_t* step_dev, int64_t row0, int64_t S,
+                           int64_t n, int64_t b, float* eps, void* stream) {
+    return philox_impl<float>(seed, stream_id, step_dev, row0, S, n, b, eps, stream);
 }
-int nsgp_philox_normal_f64(uint64_t seed, uint64_t stream_id, int64_t row0, int64_t S, int64_t n, int64_t b,
-                           double* eps, void* stream) {
-    return philox_impl<double>(seed, stream_id, row0, S, n, b, eps, stream);
+int nsgp_philox_normal_f64(uint64_t seed, uint64_t stream_id, const int64_t* step_dev, int64_t row0, int64_t S,
+                           int64_t n, int64_t b, double* eps, void* stream) {
+    return philox_impl<double>(seed, stream_id, step_dev, row0, S, n, b, eps, stream);
 }
 int nsgp_adam_step_f32(float* p, const float* g, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
-                       float beta2, float eps, int64_t step, float grad_scale, void* stream) {
+                       float beta2, float eps, int64_t step, const int64_t* step_dev, float grad_scale,
+                       void* stream) {
     if (!p) return -1; if (!g) return -2; if (!exp_avg) return -3; if (!exp_avg_sq) return -4; if (n < 0) return -5;
-    if (step < 1) return -10;
+    if (step < 1 && !step_dev) return -10;
     if (n == 0) return 0;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const double st = step < 1 ? 1.0 : (double)step;
+    const double bc1 = 1.0 - pow((double)beta1, st);
+    const double bc2 = 1.0 - pow((double)beta2, st);
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, exp_avg,
-                       exp_avg_sq, n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale);
+                       exp_avg_sq, n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale, step_dev);
     return nsgp_launch_status();
 }
 

@@ -22,11 +22,14 @@ def shard_bounds(n, world, rank):
 
 
 class PhiloxEps:
-    """settings.eps_provider callable: eps[s, i, c] keyed by (seed, step, call index, global row)."""
+    """settings.eps_provider callable: eps[s, i, c] keyed by (seed, step, call index, global row).
+    With `step_dev` (device int64, e.g. FusedAdam(capturable=True).step_dev) the step is read on the
+    device, so a captured hipGraph draws fresh noise at every replay."""
 
-    def __init__(self, seed, row0=0):
+    def __init__(self, seed, row0=0, step_dev=None):
         self.seed, self.row0 = int(seed), int(row0)
         self.step, self.call = 0, 0
+        self.step_dev = step_dev
 
     def start_step(self, step, row0=None):
         self.step, self.call = int(step), 0
@@ -37,7 +40,8 @@ class PhiloxEps:
         S, n, b = shape
         stream_id = (self.step << 32) | self.call
         self.call += 1
-        return ops.philox_normal(self.seed, stream_id, self.row0, S, n, b, dtype=dtype, device=device)
+        return ops.philox_normal(self.seed, stream_id, self.row0, S, n, b, dtype=dtype, device=device,
+                                 step_dev=self.step_dev)
 
 
 def dp_objective(mll, output, y_local, batch_global, world):

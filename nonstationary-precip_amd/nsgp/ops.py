@@ -446,23 +446,24 @@ def kl_whitened_bwd(m, Lq, gout):
     return gm.reshape(shp_m), gL.reshape(shp_L)
 
 
-def philox_normal(seed, stream_id, row0, S, n, b, dtype=torch.float32, device='cuda'):
-    """eps:(S,n,b) standard normals keyed by (seed, stream_id, global row, sample, column)."""
+def philox_normal(seed, stream_id, row0, S, n, b, dtype=torch.float32, device='cuda', step_dev=None):
+    """eps:(S,n,b) standard normals keyed by (seed, stream_id, global row, sample, column).  `step_dev`
+    (1-element int64 device tensor) replaces the high word of stream_id on the device (graph replays)."""
     eps = torch.empty((S, n, b), dtype=dtype, device=device)
     if not eps.is_cuda:
         raise BackendError('philox_normal: CUDA device required')
     with torch.cuda.device(eps.device):
-        _lib.call(f'nsgp_philox_normal_{_sfx(eps)}', ctypes.c_uint64(seed), ctypes.c_uint64(stream_id), row0, S, n,
-                  b, _p(eps), _stream())
+        _lib.call(f'nsgp_philox_normal_{_sfx(eps)}', ctypes.c_uint64(seed), ctypes.c_uint64(stream_id),
+                  _p(step_dev), row0, S, n, b, _p(eps), _stream())
     return eps
 
 
-def adam_step_(p, g, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, grad_scale=1.0):
+def adam_step_(p, g, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, grad_scale=1.0, step_dev=None):
     _chk(p, g, exp_avg, exp_avg_sq)
     if p.dtype != torch.float32 or not all(t.is_contiguous() for t in (p, g, exp_avg, exp_avg_sq)):
         raise BackendError('adam_step_: contiguous float32 flat buffers expected')
     _lib.call('nsgp_adam_step_f32', _p(p), _p(g), _p(exp_avg), _p(exp_avg_sq), p.numel(), float(lr), float(beta1),
-              float(beta2), float(eps), int(step), float(grad_scale), _stream())
+              float(beta2), float(eps), int(step), _p(step_dev), float(grad_scale), _stream())
     return p
 
 

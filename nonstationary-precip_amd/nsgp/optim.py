@@ -49,9 +49,10 @@ class FlatBucket:
 
 
 class FusedAdam:
-    """torch.optim.Adam semantics (no weight decay, no amsgrad) over a FlatBucket, one kernel per step."""
+    """torch.optim.Adam semantics (no weight decay, no amsgrad) over a FlatBucket, one kernel per step.
+    `capturable=True` keeps the step count on the device so the update can live in a hipGraph."""
 
-    def __init__(self, params, lr=0.01, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=0.01, betas=(0.9, 0.999), eps=1e-8, capturable=False):
         self.bucket = params if isinstance(params, FlatBucket) else FlatBucket(list(params))
         if self.bucket.flat_p.dtype != torch.float32:
             raise ValueError('FusedAdam: float32 parameters expected')
@@ -59,11 +60,14 @@ class FusedAdam:
         self.exp_avg = torch.zeros_like(self.bucket.flat_p)
         self.exp_avg_sq = torch.zeros_like(self.bucket.flat_p)
         self.steps = 0
+        self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.bucket.flat_p.device) if capturable else None
 
     def zero_grad(self, set_to_none=False):
         self.bucket.zero_grad()
 
     def step(self, grad_scale=1.0):
         self.steps += 1
+        if self.step_dev is not None:
+            self.step_dev.add_(1)
         ops.adam_step_(self.bucket.flat_p, self.bucket.flat_g, self.exp_avg, self.exp_avg_sq, self.lr,
-                       self.betas[0], self.betas[1], self.eps, self.steps, grad_scale)
+                       self.betas[0], self.betas[1], self.eps, self.steps, grad_scale, step_dev=self.step_dev)
