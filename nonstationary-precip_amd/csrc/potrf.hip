@@ -61,6 +61,20 @@ __device__ __forceinline__ double bcast(double v, int l) {
     return __hiloint2double(hi, lo);
 }
 
+// 1/sqrt(a) to full precision without the long v_sqrt / v_div sequences that would sit on the serial
+// pivot chain: hardware estimate + Newton steps  r <- r (1.5 - 0.5 a r^2)  (each step squares the error).
+__device__ __forceinline__ float fast_rsqrt(float a) {
+    float r = __frsqrt_rn(a);
+    r = r * (1.5f - 0.5f * a * r * r);
+    return r;
+}
+__device__ __forceinline__ double fast_rsqrt(double a) {
+    double r = __builtin_amdgcn_rsq(a);                      // ~2^-26 relative error
+    r = r * (1.5 - 0.5 * a * r * r);
+    r = r * (1.5 - 0.5 * a * r * r);
+    return r;
+}
+
 // In-register Cholesky of the block (right-looking by columns).  On exit a[j] (j <= lane) is L[lane][j],
 // a[j] (j > lane) is 0.  Returns 0 or the 1-based index of the first non-positive pivot (wave-uniform).
 template <typename T> __device__ __forceinline__ int factor_rows(T (&a)[NB], int lane) {
@@ -69,8 +83,8 @@ template <typename T> __device__ __forceinline__ int factor_rows(T (&a)[NB], int
     for (int k = 0; k < NB; ++k) {
         const T akk = bcast(a[k], k);
         if (!(akk > T(0)) && bad == 0) bad = k + 1;
-        const T piv = t_sqrt(akk);
-        const T inv = T(1) / piv;
+        const T inv = fast_rsqrt(akk);                                     // NaN for akk <= 0, flagged above
+        const T piv = akk * inv;
         const T lik = lane == k ? piv : (lane > k ? a[k] * inv : T(0));
         a[k] = lik;
 #pragma unroll
@@ -81,12 +95,17 @@ template <typename T> __device__ __forceinline__ int factor_rows(T (&a)[NB], int
 
 // Column `lane` of X = L^-1 for the lower-triangular block whose row `lane` is a[]:  x[i] = X[i][lane].
 template <typename T> __device__ __forceinline__ void invert_rows(const T (&a)[NB], T (&x)[NB], int lane) {
+    // reciprocal of this lane's diagonal element L[lane][lane] (one division, off the serial chain)
+    T dg = T(1);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) dg = (j == lane) ? a[j] : dg;
+    const T rd = T(1) / dg;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         T acc = lane == i ? T(1) : T(0);
 #pragma unroll
         for (int k = 0; k < i; ++k) acc -= bcast(a[k], i) * x[k];            // L[i][k] * X[k][lane]
-        x[i] = i < lane ? T(0) : acc / bcast(a[i], i);                      // exact zeros above the diagonal
+        x[i] = i < lane ? T(0) : acc * bcast(rd, i);                        // exact zeros above the diagonal
     }
 }
 
@@ -142,7 +161,10 @@ template <typename T>
 __global__ __launch_bounds__(64) void potrf_panel_kernel(T* __restrict__ A, int64_t n, int64_t lda, int64_t sA,
                                                          int64_t j0, T* __restrict__ wsL, int64_t npanels,
                                                          int32_t* __restrict__ info) {
-    __shared__ T Ls[NB * LDD];
+    // one dynamic LDS region (2 x 64 x 65 doubles = 66.5 KB exceeds the 64 KB static limit)
+    extern __shared__ __attribute__((aligned(16))) unsigned char panel_smem[];
+    T* Ls = reinterpret_cast<T*>(panel_smem);
+    T* Xs = Ls + NB * LDD;
     const int lane = threadIdx.x;
     const int64_t b = blockIdx.y;
     T* Ab = A + b * sA;
@@ -152,44 +174,55 @@ __global__ __launch_bounds__(64) void potrf_panel_kernel(T* __restrict__ A, int6
         if (pj > 0) writeback_panel(Ab, n, lda, wsL + (b * npanels + pj - 1) * NB * NB, pj - 1, lane);
         return;
     }
+    // All global traffic is staged through LDS so that each wave instruction reads / writes one 64-element
+    // row (coalesced), while the arithmetic works on "row `lane` in registers" (LDS row stride 65 is
+    // conflict-free for that transposed access).
     int bad;
     {
+#pragma unroll 16
+        for (int i = 0; i < NB; ++i) Ls[i * LDD + lane] = Ab[(j0 + i) * lda + j0 + lane];
+        __syncthreads();
         T a[NB];
-        const T* src = Ab + (j0 + lane) * lda + j0;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) a[j] = src[j];       // the upper part is never used (zeroed by factor_rows)
+        for (int j = 0; j < NB; ++j) a[j] = Ls[lane * LDD + j];   // the upper part is never used (zeroed by factor_rows)
         bad = factor_rows(a, lane);
 #pragma unroll
         for (int j = 0; j < NB; ++j) Ls[lane * LDD + j] = a[j];
+        T dg = T(1);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) dg = (j == lane) ? a[j] : dg;
+        Ls[lane * LDD + NB] = T(1) / dg;                 // 1 / L[lane][lane] in the pad column
     }
     __syncthreads();
     if (blockIdx.x == 0) {
         T* dst = wsL + (b * npanels + pj) * NB * NB;
+#pragma unroll 16
         for (int i = 0; i < NB; ++i) dst[i * NB + lane] = Ls[i * LDD + lane];
         if (lane == 0 && bad && info[b] == 0) info[b] = (int32_t)(j0 + bad);
     }
     const int64_t r0 = j0 + NB + (int64_t)blockIdx.x * NB;
     if (r0 >= n) return;
     const int rows = (int)((n - r0) < NB ? (n - r0) : NB);
-    const bool live = lane < rows;
     T x[NB];
     {
-        const T* src = Ab + (r0 + (live ? lane : 0)) * lda + j0;
+#pragma unroll 16
+        for (int i = 0; i < NB; ++i) Xs[i * LDD + lane] = i < rows ? Ab[(r0 + i) * lda + j0 + lane] : T(0);
+        __syncthreads();
 #pragma unroll
-        for (int j = 0; j < NB; ++j) x[j] = src[j];
+        for (int j = 0; j < NB; ++j) x[j] = Xs[lane * LDD + j];
     }
 #pragma unroll
     for (int c = 0; c < NB; ++c) {
         T acc = x[c];
 #pragma unroll
         for (int k = 0; k < c; ++k) acc -= x[k] * Ls[c * LDD + k];           // wave-uniform LDS address
-        x[c] = acc / Ls[c * LDD + c];
+        x[c] = acc * Ls[c * LDD + NB];                                       // reciprocal diagonal
     }
-    if (live) {
-        T* dst = Ab + (r0 + lane) * lda + j0;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) dst[j] = x[j];
-    }
+    for (int j = 0; j < NB; ++j) Xs[lane * LDD + j] = x[j];
+    __syncthreads();
+#pragma unroll 16
+    for (int i = 0; i < NB; ++i) if (i < rows) Ab[(r0 + i) * lda + j0 + lane] = Xs[i * LDD + lane];
 }
 
 // LAST, ragged panel (nb < 64, nothing below it): block 0 factors it in LDS, block 1 writes back panel j-1.
@@ -238,6 +271,14 @@ int potrf_impl(T* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int32_t*
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(info, 0, sizeof(int32_t) * batch, st);
     if (e != hipSuccess) return (int)e;
+    const size_t panel_lds = 2 * (size_t)NB * LDD * sizeof(T);
+    static bool attr_set = false;       // idempotent attribute, set once per process and type
+    if (!attr_set) {
+        if (panel_lds > 65536)
+            (void)hipFuncSetAttribute((const void*)potrf_panel_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)panel_lds);
+        attr_set = true;
+    }
     for (int64_t j0 = 0; j0 < n; j0 += NB) {
         const int64_t nb = (n - j0) < NB ? (n - j0) : NB;
         if (nb < NB) {
@@ -247,8 +288,8 @@ int potrf_impl(T* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int32_t*
         }
         const int64_t below = n - j0 - nb;
         const int64_t nslab = below > 0 ? cdiv64(below, NB) : 1;
-        hipLaunchKernelGGL((potrf_panel_kernel<T>), dim3((unsigned)(nslab + 1), (unsigned)batch), dim3(64), 0, st, A,
-                           n, lda, sA, j0, wsL, npanels, info);
+        hipLaunchKernelGGL((potrf_panel_kernel<T>), dim3((unsigned)(nslab + 1), (unsigned)batch), dim3(64),
+                           panel_lds, st, A, n, lda, sA, j0, wsL, npanels, info);
         if (below > 0) {
             T* L21 = A + (j0 + nb) * lda + j0;
             T* A22 = A + (j0 + nb) * lda + (j0 + nb);
@@ -275,9 +316,11 @@ __global__ __launch_bounds__(64) void trtri_diag_kernel(const T* __restrict__ L,
     if (nb == NB) {
         // registers: lane holds row `lane` of L, produces column `lane` of the inverse
         T a[NB], x[NB];
-        const T* src = Lb + (r0 + lane) * ldl + r0;
+#pragma unroll 16
+        for (int i = 0; i < NB; ++i) Ls[i * LDD + lane] = Lb[(r0 + i) * ldl + r0 + lane];      // coalesced rows
+        __syncthreads();
 #pragma unroll
-        for (int j = 0; j < NB; ++j) a[j] = src[j];
+        for (int j = 0; j < NB; ++j) a[j] = Ls[lane * LDD + j];
         invert_rows(a, x, lane);
 #pragma unroll
         for (int i = 0; i < NB; ++i) Xb[(r0 + i) * ldx + r0 + lane] = x[i];       // coalesced row stores

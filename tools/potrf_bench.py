@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the batched Kzz -> potrf -> trtri chain (3 x 1024^2 float64, as in one DSVI step)."""
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'nonstationary-precip_amd'))
+import torch  # noqa: E402
+from nsgp import ops  # noqa: E402
+
+M, b = int(os.environ.get('M', 1024)), int(os.environ.get('BATCH', 3))
+g = torch.Generator().manual_seed(0)
+Z = torch.randn(b, M, 3, generator=g, dtype=torch.float64).cuda()
+ls = torch.full((b, 3), 0.7, dtype=torch.float64).cuda()
+os_ = torch.full((b,), 0.7, dtype=torch.float64).cuda()
+K = ops.rbf_build(Z, Z, ls, os_, diag_add=1e-4)
+
+
+def timeit(fn, reps=10):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+L, info = ops.potrf(K)
+print('info', info.tolist())
+print(f'potrf  {timeit(lambda: ops.potrf(K)):8.1f} us')
+print(f'trtri  {timeit(lambda: ops.trtri(L)):8.1f} us')
