@@ -82,6 +82,18 @@ def build(device, dp_world):
     return model, mll, opt
 
 
+def host_cores():
+    """CPU threads this process may actually use: cgroup quota if set, else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(x, y, idx, seconds_budget=25.0):
     """The oracle's gpytorch-mirroring op sequence (float32, float64 Cholesky/solve, per-sample Kzz
     recomputation) for the same model/minibatch on the host cores: forward + backward + Adam."""
@@ -300,7 +312,7 @@ def main():
         if world == 1:
             result.update(gibbs_chol_ms(device))
             if not args.no_cpu_baseline:
-                torch.set_num_threads(os.cpu_count() or 1)
+                torch.set_num_threads(host_cores())
                 v, nsteps = cpu_baseline(x_all, y_all, idx)
                 result['cpu_baseline'] = {'value': round(v, 4), 'unit': 'steps/s', 'cores': torch.get_num_threads(),
                                           'kind': 'port',

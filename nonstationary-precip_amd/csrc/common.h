@@ -37,6 +37,19 @@ template <> __device__ __forceinline__ double t_exp<double>(double x) { return e
 template <typename T> __device__ __forceinline__ T t_sqrt(T x);
 template <> __device__ __forceinline__ float t_sqrt<float>(float x) { return sqrtf(x); }
 template <> __device__ __forceinline__ double t_sqrt<double>(double x) { return sqrt(x); }
+// fp32: single hardware instructions (v_rcp_f32 / v_sqrt_f32 / v_exp_f32, ~1 ulp) keep the build kernels
+// HBM-bound instead of VALU-bound; fp64 uses the full-precision library sequences.
+template <typename T> __device__ __forceinline__ T t_rcp(T x);
+template <> __device__ __forceinline__ float t_rcp<float>(float x) { return __builtin_amdgcn_rcpf(x); }
+template <> __device__ __forceinline__ double t_rcp<double>(double x) { return 1.0 / x; }
+template <typename T> __device__ __forceinline__ T t_fsqrt(T x);
+template <> __device__ __forceinline__ float t_fsqrt<float>(float x) { return __builtin_amdgcn_sqrtf(x); }
+template <> __device__ __forceinline__ double t_fsqrt<double>(double x) { return sqrt(x); }
+template <typename T> __device__ __forceinline__ T t_fexp(T x);      // exp(x), x <= 0 on this path
+template <> __device__ __forceinline__ float t_fexp<float>(float x) {
+    return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
+}
+template <> __device__ __forceinline__ double t_fexp<double>(double x) { return exp(x); }
 template <typename T> __device__ __forceinline__ T t_log(T x);
 template <> __device__ __forceinline__ float t_log<float>(float x) { return logf(x); }
 template <> __device__ __forceinline__ double t_log<double>(double x) { return log(x); }

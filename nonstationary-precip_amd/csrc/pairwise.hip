@@ -62,13 +62,13 @@ template <typename T, int D> struct GibbsOp {
         for (int d = 0; d < DM; ++d) {
             if (D || d < Drt) {
                 const T s = r.l[d] * r.l[d] + c.l[d] * c.l[d];
-                const T inv = T(1) / s;
+                const T inv = t_rcp(s);
                 const T df = r.x[d] - c.x[d];
                 pre *= T(2) * r.l[d] * c.l[d] * inv;
                 ex += df * df * inv;
             }
         }
-        return t_sqrt(pre) * t_exp(-ex);
+        return t_fsqrt(pre) * t_fexp(-ex);
     }
     __device__ __forceinline__ T eval(int64_t, const P& r, const P& c) const { return os() * base(r, c); }
     // accumulate g * d k / d(param) into row / col / global accumulators
@@ -122,7 +122,7 @@ template <typename T, int D> struct RbfOp {
             const T df = r.x[d] - c.x[d];
             ex += df * df;
         }
-        return t_exp(T(-0.5) * ex);
+        return t_fexp(T(-0.5) * ex);
     }
     __device__ __forceinline__ T eval(int64_t b, const P& r, const P& c) const { return os[b] * base(r, c); }
     // row/col accumulators are in units of d/d(x/ls) ("scaled x"); pass 2 divides by ls.
