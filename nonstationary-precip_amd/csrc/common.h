@@ -42,6 +42,14 @@ template <> __device__ __forceinline__ double t_sqrt<double>(double x) { return 
 template <typename T> __device__ __forceinline__ T t_rcp(T x);
 template <> __device__ __forceinline__ float t_rcp<float>(float x) { return __builtin_amdgcn_rcpf(x); }
 template <> __device__ __forceinline__ double t_rcp<double>(double x) { return 1.0 / x; }
+template <typename T> __device__ __forceinline__ T t_rsqrt(T x);     // 1/sqrt(x), full precision
+template <> __device__ __forceinline__ float t_rsqrt<float>(float x) { return __builtin_amdgcn_rsqf(x); }
+template <> __device__ __forceinline__ double t_rsqrt<double>(double x) {
+    double r = __builtin_amdgcn_rsq(x);                      // ~2^-26 relative; two Newton steps -> ~1 ulp
+    r = r * (1.5 - 0.5 * x * r * r);
+    r = r * (1.5 - 0.5 * x * r * r);
+    return r;
+}
 template <typename T> __device__ __forceinline__ T t_fsqrt(T x);
 template <> __device__ __forceinline__ float t_fsqrt<float>(float x) { return __builtin_amdgcn_sqrtf(x); }
 template <> __device__ __forceinline__ double t_fsqrt<double>(double x) { return sqrt(x); }

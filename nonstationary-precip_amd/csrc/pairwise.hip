@@ -3,9 +3,10 @@
 //   K1 Gibbs (models/gibbs_kernels.py:154-162), K2 batched RBF-ARD (gpytorch ScaleKernel(RBF),
 //   models/dgps.py:44-46), K3 Paciorek-Schervish D=2 (models/multivariate_gibbs_kernel.py:98-150).
 //
-// Forward: HBM-write bound.  One 256-thread workgroup owns a 32 x (64*CPT) tile; a lane owns CPT
+// Forward: HBM-write bound.  One 256-thread workgroup owns a 64 x (64*CPT) tile; a lane owns CPT
 // consecutive columns (16 B) so every wave store is one contiguous 1 KiB line group; the column
-// operands live in registers for the whole tile and the row operands are wave-uniform loads.
+// operands live in registers for the whole tile and the row operands are computed once per tile and
+// broadcast-read from LDS.
 // Algorithmic bytes per build: s*(n1*n2 + 2*D*(n1+n2)).
 //
 // Backward: one pass over G (dLoss/dK).  A workgroup owns a 64 x 256 tile: wave w walks rows
@@ -34,41 +35,41 @@ template <typename T, int D> struct GibbsOp {
     int Drt;
     const T* osp;                          // device scalar or nullptr (= 1)
     __device__ __forceinline__ T os() const { return osp ? osp[0] : T(1); }
-    struct P { T x[DM]; T l[DM]; };
-    __device__ __forceinline__ P row(int64_t, int64_t i) const {
+    // per-point operands: x, l, q = l^2 and h = sqrt(prod_d sqrt(2) l_d), so that
+    //   k = prod_d sqrt(2 l1 l2 / s_d) * exp(-sum_d delta_d^2 / s_d),   s_d = q1_d + q2_d
+    //     = h1 h2 rsqrt(S) * exp(-(sum_d delta_d^2 prod_{e != d} s_e) / S),   S = prod_d s_d
+    // costs ONE rsqrt and ONE exp per matrix entry (the per-point sqrt is amortised over a tile).
+    struct P { T x[DM]; T l[DM]; T q[DM]; T h; };
+    __device__ __forceinline__ P point(const T* x, const T* l, int64_t n, int64_t i) const {
         P p;
+        T hp = T(1);
 #pragma unroll
         for (int d = 0; d < DM; ++d) {
             const bool on = D || d < Drt;
-            p.x[d] = on ? x1[i * Drt + d] : T(0);
-            p.l[d] = on ? l1[(int64_t)d * n1 + i] : T(1);
+            p.x[d] = on ? x[i * Drt + d] : T(0);
+            p.l[d] = on ? l[(int64_t)d * n + i] : T(1);
+            p.q[d] = p.l[d] * p.l[d];
+            if (on) hp *= T(1.4142135623730951) * p.l[d];
         }
+        p.h = t_fsqrt(hp);
         return p;
     }
-    __device__ __forceinline__ P col(int64_t, int64_t j) const {
-        P p;
-#pragma unroll
-        for (int d = 0; d < DM; ++d) {
-            const bool on = D || d < Drt;
-            p.x[d] = on ? x2[j * Drt + d] : T(0);
-            p.l[d] = on ? l2[(int64_t)d * n2 + j] : T(1);
-        }
-        return p;
-    }
-    // unscaled kernel value (pre * exp)
+    __device__ __forceinline__ P row(int64_t, int64_t i) const { return point(x1, l1, n1, i); }
+    __device__ __forceinline__ P col(int64_t, int64_t j) const { return point(x2, l2, n2, j); }
+    // unscaled kernel value
     __device__ __forceinline__ T base(const P& r, const P& c) const {
-        T pre = T(1), ex = T(0);
+        T S = T(1), num = T(0);
 #pragma unroll
         for (int d = 0; d < DM; ++d) {
             if (D || d < Drt) {
-                const T s = r.l[d] * r.l[d] + c.l[d] * c.l[d];
-                const T inv = t_rcp(s);
+                const T s = r.q[d] + c.q[d];
                 const T df = r.x[d] - c.x[d];
-                pre *= T(2) * r.l[d] * c.l[d] * inv;
-                ex += df * df * inv;
+                num = num * s + df * df * S;               // sum_d delta_d^2 prod_{e != d} s_e, built incrementally
+                S *= s;
             }
         }
-        return t_fsqrt(pre) * t_fexp(-ex);
+        const T rs = t_rsqrt(S);
+        return r.h * c.h * rs * t_fexp(-num * rs * rs);
     }
     __device__ __forceinline__ T eval(int64_t, const P& r, const P& c) const { return os() * base(r, c); }
     // accumulate g * d k / d(param) into row / col / global accumulators
@@ -198,17 +199,21 @@ template <typename T> struct PsOp {
 // ------------------------------------------------------------------------------------------
 // forward tile kernel
 // ------------------------------------------------------------------------------------------
-constexpr int FWD_TI = 32;
+constexpr int FWD_TI = 64;
 
 template <typename T, typename Op>
 __global__ __launch_bounds__(256) void pairwise_fwd_kernel(Op op, int64_t n1, int64_t n2, T diag_add_v,
                                                            const T* __restrict__ diag_add_p,
                                                            T* __restrict__ K, int64_t ldk, int64_t sK, int vec_ok) {
     constexpr int CPT = Cpt<T>::v;
+    __shared__ typename Op::P rows_s[FWD_TI];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t b = blockIdx.z;
     const int64_t j0 = ((int64_t)blockIdx.x * 64 + lane) * CPT;
     const int64_t i0 = (int64_t)blockIdx.y * FWD_TI;
+    // row operands of the tile: computed once (one thread per row), then broadcast-read from LDS
+    if (threadIdx.x < FWD_TI && i0 + threadIdx.x < n1) rows_s[threadIdx.x] = op.row(b, i0 + threadIdx.x);
+    __syncthreads();
     if (j0 >= n2) return;
     const T diag_add = diag_add_p ? diag_add_p[0] : diag_add_v;
     typename Op::P cols[CPT];
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(256) void pairwise_fwd_kernel(Op op, int64_t n1, in
     for (int r = w; r < FWD_TI; r += 4) {
         const int64_t i = i0 + r;
         if (i >= n1) break;
-        const typename Op::P rp = op.row(b, i);
+        const typename Op::P rp = rows_s[r];
         T v[CPT];
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {

@@ -144,85 +144,188 @@ template <typename T> __device__ int factor_lds(T* Ls, int nb, int lane) {
 
 // write-back of panel p's factor (side buffer -> A) + zero the strict upper part of its rows
 template <typename T>
-__device__ __forceinline__ void writeback_panel(T* Ab, int64_t n, int64_t lda, const T* src, int64_t p, int lane) {
+__device__ __forceinline__ void writeback_panel(T* Ab, int64_t n, int64_t lda, const T* src, int64_t p, int tid,
+                                                int nthreads = 64) {
     const int64_t r0 = p * NB;
     const int pnb = (int)((n - r0) < NB ? (n - r0) : NB);
     for (int i = 0; i < pnb; ++i) {
-        if (lane <= i) Ab[(r0 + i) * lda + r0 + lane] = src[i * NB + lane];
-        for (int64_t c = r0 + i + 1 + lane; c < n; c += 64) Ab[(r0 + i) * lda + c] = T(0);
+        if (tid <= i) Ab[(r0 + i) * lda + r0 + tid] = src[i * NB + tid];
+        for (int64_t c = r0 + i + 1 + tid; c < n; c += nthreads) Ab[(r0 + i) * lda + c] = T(0);
     }
 }
 
-// FULL 64-wide panel.  grid.x = nslab + 1 one-wave workgroups: blocks [0, nslab) each factor the diagonal
-// block in registers (redundantly: ~10 us of VALU, no grid-wide dependency) and solve their own
-// 64-row slab of the panel, L21 = A21 L11^-T, by forward substitution with L11 broadcast from LDS;
-// block 0 publishes L11 to the side buffer; the last block writes panel j-1's factor back into A.
+// 16x16x4 MFMA (both precisions have one) for the in-panel block operations.
+template <typename T> struct Mma16;
+template <> struct Mma16<double> {
+    typedef double acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int crow(int r, int lane) { return (lane >> 4) + 4 * r; }
+};
+template <> struct Mma16<float> {
+    typedef float acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int crow(int r, int lane) { return 4 * (lane >> 4) + r; }
+};
+constexpr int SB = 16;          // sub-block of the panel
+constexpr int LDI = SB + 1;
+
+// Sub-panel step of the 64x64 diagonal block held in LDS (S, leading dimension LDD): ONE wave takes
+// columns [c0, c0+16) with row `lane` in registers, factors them (16 pivots, v_readlane broadcasts),
+// and writes them back.  Lanes < c0 write zeros (upper part of L).
+template <typename T, int C0> __device__ __forceinline__ int factor_subpanel(T* S, int lane) {
+    T a[SB];
+#pragma unroll
+    for (int j = 0; j < SB; ++j) a[j] = S[lane * LDD + C0 + j];
+    int bad = 0;
+#pragma unroll
+    for (int k = 0; k < SB; ++k) {
+        const int p = C0 + k;
+        const T akk = bcast(a[k], p);
+        if (!(akk > T(0)) && bad == 0) bad = p + 1;
+        const T inv = fast_rsqrt(akk);
+        const T piv = akk * inv;
+        const T lik = lane == p ? piv : (lane > p ? a[k] * inv : T(0));
+        a[k] = lik;
+#pragma unroll
+        for (int j = k + 1; j < SB; ++j) a[j] -= lik * bcast(lik, C0 + j);
+    }
+#pragma unroll
+    for (int j = 0; j < SB; ++j) S[lane * LDD + C0 + j] = a[j];
+    return bad;
+}
+
+// FULL 64-wide panel.  grid.x = nslab + 1 workgroups of 4 waves.  Blocks [0, nslab) each factor the
+// diagonal block in LDS (redundantly: no grid-wide dependency) -- 4 sub-panels of 16 columns, each factored
+// by wave 0 in registers, the rest of the block updated by all waves with 16x16x4 MFMAs -- invert the four
+// 16x16 diagonal sub-blocks, and solve their own 64-row slab  L21 = A21 L11^-T  by blocked substitution
+// (MFMA updates, multiplication by the 16x16 inverses).  The slab's global loads are issued before the
+// factorisation so their latency is hidden.  Block 0 publishes L11 to the side buffer; the last block
+// writes panel j-1's factor back into A.
 template <typename T>
-__global__ __launch_bounds__(64) void potrf_panel_kernel(T* __restrict__ A, int64_t n, int64_t lda, int64_t sA,
-                                                         int64_t j0, T* __restrict__ wsL, int64_t npanels,
-                                                         int32_t* __restrict__ info) {
-    // one dynamic LDS region (2 x 64 x 65 doubles = 66.5 KB exceeds the 64 KB static limit)
+__global__ __launch_bounds__(256) void potrf_panel_kernel(T* __restrict__ A, int64_t n, int64_t lda, int64_t sA,
+                                                          int64_t j0, T* __restrict__ wsL, int64_t npanels,
+                                                          int32_t* __restrict__ info) {
+    typedef Mma16<T> MM;
+    typedef typename MM::acc_t acc_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char panel_smem[];
-    T* Ls = reinterpret_cast<T*>(panel_smem);
-    T* Xs = Ls + NB * LDD;
-    const int lane = threadIdx.x;
+    T* S = reinterpret_cast<T*>(panel_smem);            // [64][LDD]   diagonal block -> L11
+    T* Xs = S + NB * LDD;                               // [64][LDD]   this workgroup's slab
+    T* Dinv = Xs + NB * LDD;                            // [4][16][LDI] inverses of the 16x16 diagonal sub-blocks
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t b = blockIdx.y;
     T* Ab = A + b * sA;
     const int64_t pj = j0 / NB;
     const int nslab = (int)gridDim.x - 1;
     if ((int)blockIdx.x == nslab) {
-        if (pj > 0) writeback_panel(Ab, n, lda, wsL + (b * npanels + pj - 1) * NB * NB, pj - 1, lane);
+        if (pj > 0) writeback_panel(Ab, n, lda, wsL + (b * npanels + pj - 1) * NB * NB, pj - 1, tid, 256);
         return;
     }
-    // All global traffic is staged through LDS so that each wave instruction reads / writes one 64-element
-    // row (coalesced), while the arithmetic works on "row `lane` in registers" (LDS row stride 65 is
-    // conflict-free for that transposed access).
-    int bad;
-    {
-#pragma unroll 16
-        for (int i = 0; i < NB; ++i) Ls[i * LDD + lane] = Ab[(j0 + i) * lda + j0 + lane];
-        __syncthreads();
-        T a[NB];
+    const int64_t r0 = j0 + NB + (int64_t)blockIdx.x * NB;
+    const int rows = r0 >= n ? 0 : (int)((n - r0) < NB ? (n - r0) : NB);
+    // global -> LDS: wave w takes rows [16w, 16w+16) of both blocks, one coalesced 64-element row per
+    // instruction; the slab rows stay in registers until the factorisation is done.
+    T xr[SB];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) a[j] = Ls[lane * LDD + j];   // the upper part is never used (zeroed by factor_rows)
-        bad = factor_rows(a, lane);
+    for (int i = 0; i < SB; ++i) S[(w * SB + i) * LDD + lane] = Ab[(j0 + w * SB + i) * lda + j0 + lane];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) Ls[lane * LDD + j] = a[j];
-        T dg = T(1);
-#pragma unroll
-        for (int j = 0; j < NB; ++j) dg = (j == lane) ? a[j] : dg;
-        Ls[lane * LDD + NB] = T(1) / dg;                 // 1 / L[lane][lane] in the pad column
-    }
+    for (int i = 0; i < SB; ++i) xr[i] = (w * SB + i) < rows ? Ab[(r0 + w * SB + i) * lda + j0 + lane] : T(0);
     __syncthreads();
+
+    const int fm = lane & 15, fk = lane >> 4;            // MFMA operand lane -> (m|n, k)
+    int bad = 0;
+#define NSGP_SUBPANEL(C0)                                                                             \
+    {                                                                                                 \
+        if (w == 0) { const int bd = factor_subpanel<T, C0>(S, lane); if (bad == 0) bad = bd; }       \
+        __syncthreads();                                                                              \
+        constexpr int B0 = C0 / SB;                                                                   \
+        constexpr int NT = (3 - B0) * (4 - B0) / 2;      /* lower tiles of the trailing block */      \
+        for (int q = w; q < NT; q += 4) {                                                             \
+            int ti = B0 + 1, tj = B0 + 1, c = q;                                                      \
+            while (c > ti - (B0 + 1)) { c -= ti - B0; ++ti; }                                         \
+            tj = B0 + 1 + c;                                                                          \
+            acc_t acc;                                                                                \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r)                                             \
+                acc[r] = S[(ti * SB + MM::crow(r, lane)) * LDD + tj * SB + fm];                       \
+            _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                        \
+                const T av = -S[(ti * SB + fm) * LDD + C0 + 4 * kk + fk];                             \
+                const T bv = S[(tj * SB + fm) * LDD + C0 + 4 * kk + fk];                              \
+                acc = MM::mma(av, bv, acc);                                                           \
+            }                                                                                         \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r)                                             \
+                S[(ti * SB + MM::crow(r, lane)) * LDD + tj * SB + fm] = acc[r];                       \
+        }                                                                                             \
+        if (NT > 0) __syncthreads();                                                                  \
+    }
+    NSGP_SUBPANEL(0)
+    NSGP_SUBPANEL(16)
+    NSGP_SUBPANEL(32)
+    NSGP_SUBPANEL(48)
+#undef NSGP_SUBPANEL
+
+    // inverse of diagonal sub-block w: lane c < 16 builds column c by forward substitution
+    if (lane < SB) {
+        const T* Lw = S + (w * SB) * LDD + w * SB;
+        T x[SB];
+#pragma unroll
+        for (int i = 0; i < SB; ++i) {
+            T acc = lane == i ? T(1) : T(0);
+#pragma unroll
+            for (int k = 0; k < i; ++k) acc -= Lw[i * LDD + k] * x[k];
+            x[i] = i < lane ? T(0) : acc / Lw[i * LDD + i];
+        }
+#pragma unroll
+        for (int i = 0; i < SB; ++i) Dinv[(w * SB + i) * LDI + lane] = x[i];
+    }
+#pragma unroll
+    for (int i = 0; i < SB; ++i) Xs[(w * SB + i) * LDD + lane] = xr[i];
+    __syncthreads();
+
     if (blockIdx.x == 0) {
         T* dst = wsL + (b * npanels + pj) * NB * NB;
-#pragma unroll 16
-        for (int i = 0; i < NB; ++i) dst[i * NB + lane] = Ls[i * LDD + lane];
-        if (lane == 0 && bad && info[b] == 0) info[b] = (int32_t)(j0 + bad);
+#pragma unroll
+        for (int i = 0; i < SB; ++i) dst[(w * SB + i) * NB + lane] = S[(w * SB + i) * LDD + lane];
+        if (tid == 0 && bad && info[b] == 0) info[b] = (int32_t)(j0 + bad);
     }
-    const int64_t r0 = j0 + NB + (int64_t)blockIdx.x * NB;
-    if (r0 >= n) return;
-    const int rows = (int)((n - r0) < NB ? (n - r0) : NB);
-    T x[NB];
-    {
-#pragma unroll 16
-        for (int i = 0; i < NB; ++i) Xs[i * LDD + lane] = i < rows ? Ab[(r0 + i) * lda + j0 + lane] : T(0);
+    if (rows == 0) return;                               // workgroup-uniform
+
+    // slab strip of wave w: rows [16w, 16w+16).  X_cb = (A_cb - sum_{kb<cb} X_kb L[cb][kb]^T) Dinv_cb^T
+    T* Xw = Xs + (w * SB) * LDD;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        acc_t acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = Xw[MM::crow(r, lane) * LDD + cb * SB + fm];
+#pragma unroll
+        for (int kb = 0; kb < cb; ++kb)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const T av = -Xw[fm * LDD + kb * SB + 4 * kk + fk];
+                const T bv = S[(cb * SB + fm) * LDD + kb * SB + 4 * kk + fk];
+                acc = MM::mma(av, bv, acc);
+            }
+        __syncthreads();                                 // (uniform) all reads of the strip issued before it is overwritten
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Xw[MM::crow(r, lane) * LDD + cb * SB + fm] = acc[r];
+        __syncthreads();
+        acc_t y = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const T av = Xw[fm * LDD + cb * SB + 4 * kk + fk];
+            const T bv = Dinv[(cb * SB + fm) * LDI + 4 * kk + fk];
+            y = MM::mma(av, bv, y);
+        }
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < NB; ++j) x[j] = Xs[lane * LDD + j];
+        for (int r = 0; r < 4; ++r) Xw[MM::crow(r, lane) * LDD + cb * SB + fm] = y[r];
+        __syncthreads();
     }
 #pragma unroll
-    for (int c = 0; c < NB; ++c) {
-        T acc = x[c];
-#pragma unroll
-        for (int k = 0; k < c; ++k) acc -= x[k] * Ls[c * LDD + k];           // wave-uniform LDS address
-        x[c] = acc * Ls[c * LDD + NB];                                       // reciprocal diagonal
-    }
-#pragma unroll
-    for (int j = 0; j < NB; ++j) Xs[lane * LDD + j] = x[j];
-    __syncthreads();
-#pragma unroll 16
-    for (int i = 0; i < NB; ++i) if (i < rows) Ab[(r0 + i) * lda + j0 + lane] = Xs[i * LDD + lane];
+    for (int i = 0; i < SB; ++i)
+        if (w * SB + i < rows) Ab[(r0 + w * SB + i) * lda + j0 + lane] = Xw[i * LDD + lane];
 }
 
 // LAST, ragged panel (nb < 64, nothing below it): block 0 factors it in LDS, block 1 writes back panel j-1.
@@ -271,7 +374,7 @@ int potrf_impl(T* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int32_t*
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(info, 0, sizeof(int32_t) * batch, st);
     if (e != hipSuccess) return (int)e;
-    const size_t panel_lds = 2 * (size_t)NB * LDD * sizeof(T);
+    const size_t panel_lds = (2 * (size_t)NB * LDD + 4 * SB * LDI) * sizeof(T);
     static bool attr_set = false;       // idempotent attribute, set once per process and type
     if (!attr_set) {
         if (panel_lds > 65536)
@@ -288,7 +391,7 @@ int potrf_impl(T* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int32_t*
         }
         const int64_t below = n - j0 - nb;
         const int64_t nslab = below > 0 ? cdiv64(below, NB) : 1;
-        hipLaunchKernelGGL((potrf_panel_kernel<T>), dim3((unsigned)(nslab + 1), (unsigned)batch), dim3(64),
+        hipLaunchKernelGGL((potrf_panel_kernel<T>), dim3((unsigned)(nslab + 1), (unsigned)batch), dim3(256),
                            panel_lds, st, A, n, lda, sA, j0, wsL, npanels, info);
         if (below > 0) {
             T* L21 = A + (j0 + nb) * lda + j0;

@@ -84,13 +84,23 @@ def _gibbs_args(x1, x2, ell1, ell2):
     return ref, n1, n2, D
 
 
-def gibbs_build(x1, x2, ell1, ell2, outputscale=None, diag_add=None):
+def _out_matrix(out, shape, ref):
+    """Validate a caller-provided contiguous output buffer (or allocate one)."""
+    if out is None:
+        return torch.empty(shape, dtype=ref.dtype, device=ref.device)
+    if tuple(out.shape) != tuple(shape) or out.dtype != ref.dtype or out.device != ref.device \
+            or not out.is_contiguous():
+        raise BackendError(f'out: contiguous {tuple(shape)} {ref.dtype} tensor on {ref.device} expected')
+    return out
+
+
+def gibbs_build(x1, x2, ell1, ell2, outputscale=None, diag_add=None, out=None):
     """K = os * Gibbs(x1,x2; ell1,ell2) (+ diag_add on the diagonal).  models/gibbs_kernels.py:154-162."""
     ref, n1, n2, D = _gibbs_args(x1, x2, ell1, ell2)
     x1, x2, ell1, ell2 = _c(x1), _c(x2), _c(ell1), _c(ell2)
     os_ = None if outputscale is None else _scalar_dev(outputscale, ref)
     da = None if diag_add is None else _scalar_dev(diag_add, ref)
-    K = torch.empty((n1, n2), dtype=ref.dtype, device=ref.device)
+    K = _out_matrix(out, (n1, n2), ref)
     _lib.call(f'nsgp_gibbs_build_fwd_{_sfx(ref)}', _p(x1), _p(x2), _p(ell1), _p(ell2), n1, n2, D,
               _p(os_), _p(da), _p(K), n2, _stream())
     return K
@@ -141,10 +151,10 @@ def _rbf_args(x1, x2, ls, os_):
     return ref, x1, x2, _c(ls), _c(os_), batch, n1, n2, D, sx1, sx2
 
 
-def rbf_build(x1, x2, ls, os_, diag_add=0.0):
+def rbf_build(x1, x2, ls, os_, diag_add=0.0, out=None):
     """K[b] = os[b] * exp(-0.5 |(x1-x2)/ls[b]|^2) (+diag_add I).  x:(n,D) shared or (batch,n,D)."""
     ref, x1, x2, ls, os_, batch, n1, n2, D, sx1, sx2 = _rbf_args(x1, x2, ls, os_)
-    K = torch.empty((batch, n1, n2), dtype=ref.dtype, device=ref.device)
+    K = _out_matrix(out, (batch, n1, n2), ref)
     _lib.call(f'nsgp_rbf_build_fwd_{_sfx(ref)}', _p(x1), _p(x2), _p(ls), _p(os_), batch, n1, n2, D, sx1, sx2,
               float(diag_add), _p(K), n2, n1 * n2, _stream())
     return K

@@ -36,12 +36,14 @@ class WhitenFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, jitter, chol_bwd_f64, *params):
         groups = [params[i:i + 3] for i in range(0, len(params), 3)]
-        Ks, z64 = [], []
-        for Z, ls, os_ in groups:
+        z64, off = [], 0
+        M = groups[0][0].shape[-2]
+        K = torch.empty((sum(g[0].shape[0] for g in groups), M, M), dtype=torch.float64, device=groups[0][0].device)
+        for Z, ls, os_ in groups:                # every group's Gram matrices straight into the batched buffer
             Zd, lsd, osd = Z.double(), ls.double(), os_.double()
             z64.append((Zd, lsd, osd))
-            Ks.append(ops.rbf_build(Zd, Zd, lsd, osd, diag_add=jitter))
-        K = Ks[0] if len(Ks) == 1 else torch.cat(Ks, dim=0)
+            ops.rbf_build(Zd, Zd, lsd, osd, diag_add=jitter, out=K[off:off + Z.shape[0]])
+            off += Z.shape[0]
         L, info = ops.potrf(K, overwrite=True)
         W64 = ops.trtri(L)
         ctx.save_for_backward(W64, *[t for g in z64 for t in g])
