@@ -142,18 +142,6 @@ template <typename T> __device__ int factor_lds(T* Ls, int nb, int lane) {
     return bad;
 }
 
-// write-back of panel p's factor (side buffer -> A) + zero the strict upper part of its rows
-template <typename T>
-__device__ __forceinline__ void writeback_panel(T* Ab, int64_t n, int64_t lda, const T* src, int64_t p, int tid,
-                                                int nthreads = 64) {
-    const int64_t r0 = p * NB;
-    const int pnb = (int)((n - r0) < NB ? (n - r0) : NB);
-    for (int i = 0; i < pnb; ++i) {
-        if (tid <= i) Ab[(r0 + i) * lda + r0 + tid] = src[i * NB + tid];
-        for (int64_t c = r0 + i + 1 + tid; c < n; c += nthreads) Ab[(r0 + i) * lda + c] = T(0);
-    }
-}
-
 // 16x16x4 MFMA (both precisions have one) for the in-panel block operations.
 template <typename T> struct Mma16;
 template <> struct Mma16<double> {
@@ -170,13 +158,17 @@ template <> struct Mma16<float> {
     }
     static __device__ __forceinline__ int crow(int r, int lane) { return 4 * (lane >> 4) + r; }
 };
+// Pins a loaded value in a register: stops the compiler from sinking a clamped (always valid) load under the
+// bounds condition of its later select, which would turn N independent loads into N serialized
+// load -> s_waitcnt -> use round trips (measured: 13 us instead of 5 for the rank-64 update).
+template <typename T> __device__ __forceinline__ void keep(T& v) { asm volatile("" : "+v"(v)); }
 constexpr int SB = 16;          // sub-block of the panel
 constexpr int LDI = SB + 1;
 
 // Sub-panel step of the 64x64 diagonal block held in LDS (S, leading dimension LDD): ONE wave takes
 // columns [c0, c0+16) with row `lane` in registers, factors them (16 pivots, v_readlane broadcasts),
 // and writes them back.  Lanes < c0 write zeros (upper part of L).
-template <typename T, int C0> __device__ __forceinline__ int factor_subpanel(T* S, int lane) {
+template <typename T, int C0> __device__ __forceinline__ int factor_subpanel(T* S, T* rd, int lane) {
     T a[SB];
 #pragma unroll
     for (int j = 0; j < SB; ++j) a[j] = S[lane * LDD + C0 + j];
@@ -188,6 +180,7 @@ template <typename T, int C0> __device__ __forceinline__ int factor_subpanel(T* 
         if (!(akk > T(0)) && bad == 0) bad = p + 1;
         const T inv = fast_rsqrt(akk);
         const T piv = akk * inv;
+        if (lane == 0) rd[p] = inv;                                          // 1 / L[p][p]
         const T lik = lane == p ? piv : (lane > p ? a[k] * inv : T(0));
         a[k] = lik;
 #pragma unroll
@@ -198,13 +191,31 @@ template <typename T, int C0> __device__ __forceinline__ int factor_subpanel(T* 
     return bad;
 }
 
-// FULL 64-wide panel.  grid.x = nslab + 1 workgroups of 4 waves.  Blocks [0, nslab) each factor the
+// Inverse of the 16x16 diagonal sub-block B0 of the factored block: lane c < 16 builds column c by forward
+// substitution (L rows are broadcast reads from LDS, reciprocal pivots from rd).
+template <typename T> __device__ __forceinline__ void invert_subblock(const T* S, const T* rd, T* Dinv, int B0,
+                                                                      int lane) {
+    if (lane >= SB) return;
+    const T* Lw = S + (B0 * SB) * LDD + B0 * SB;
+    T x[SB];
+#pragma unroll
+    for (int i = 0; i < SB; ++i) {
+        T acc = lane == i ? T(1) : T(0);
+#pragma unroll
+        for (int k = 0; k < i; ++k) acc -= Lw[i * LDD + k] * x[k];
+        x[i] = i < lane ? T(0) : acc * rd[B0 * SB + i];
+    }
+#pragma unroll
+    for (int i = 0; i < SB; ++i) Dinv[(B0 * SB + i) * LDI + lane] = x[i];
+}
+
+// FULL 64-wide panel.  grid.x = nslab workgroups of 4 waves, each factors the
 // diagonal block in LDS (redundantly: no grid-wide dependency) -- 4 sub-panels of 16 columns, each factored
 // by wave 0 in registers, the rest of the block updated by all waves with 16x16x4 MFMAs -- invert the four
 // 16x16 diagonal sub-blocks, and solve their own 64-row slab  L21 = A21 L11^-T  by blocked substitution
 // (MFMA updates, multiplication by the 16x16 inverses).  The slab's global loads are issued before the
-// factorisation so their latency is hidden.  Block 0 publishes L11 to the side buffer; the last block
-// writes panel j-1's factor back into A.
+// factorisation so their latency is hidden.  Block 0 publishes L11 to the side buffer (other workgroups
+// still read A11); potrf_finalize_kernel copies the factors into place at the end.
 template <typename T>
 __global__ __launch_bounds__(256) void potrf_panel_kernel(T* __restrict__ A, int64_t n, int64_t lda, int64_t sA,
                                                           int64_t j0, T* __restrict__ wsL, int64_t npanels,
@@ -215,33 +226,43 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(T* __restrict__ A, int
     T* S = reinterpret_cast<T*>(panel_smem);            // [64][LDD]   diagonal block -> L11
     T* Xs = S + NB * LDD;                               // [64][LDD]   this workgroup's slab
     T* Dinv = Xs + NB * LDD;                            // [4][16][LDI] inverses of the 16x16 diagonal sub-blocks
+    T* rd = Dinv + 4 * SB * LDI;                        // [64] reciprocal pivots
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t b = blockIdx.y;
     T* Ab = A + b * sA;
     const int64_t pj = j0 / NB;
-    const int nslab = (int)gridDim.x - 1;
-    if ((int)blockIdx.x == nslab) {
-        if (pj > 0) writeback_panel(Ab, n, lda, wsL + (b * npanels + pj - 1) * NB * NB, pj - 1, tid, 256);
-        return;
-    }
     const int64_t r0 = j0 + NB + (int64_t)blockIdx.x * NB;
     const int rows = r0 >= n ? 0 : (int)((n - r0) < NB ? (n - r0) : NB);
     // global -> LDS: wave w takes rows [16w, 16w+16) of both blocks, one coalesced 64-element row per
     // instruction; the slab rows stay in registers until the factorisation is done.
     T xr[SB];
+    {
+        T dr[SB];                                        // loads first, LDS stores after (one exposed latency)
 #pragma unroll
-    for (int i = 0; i < SB; ++i) S[(w * SB + i) * LDD + lane] = Ab[(j0 + w * SB + i) * lda + j0 + lane];
+        for (int i = 0; i < SB; ++i) dr[i] = Ab[(j0 + w * SB + i) * lda + j0 + lane];
 #pragma unroll
-    for (int i = 0; i < SB; ++i) xr[i] = (w * SB + i) < rows ? Ab[(r0 + w * SB + i) * lda + j0 + lane] : T(0);
+        for (int i = 0; i < SB; ++i) {                   // clamped row: unconditional loads (no branch per load)
+            const int64_t rr = r0 + w * SB + i;
+            xr[i] = Ab[(rr < n ? rr : n - 1) * lda + j0 + lane];
+        }
+#pragma unroll
+        for (int i = 0; i < SB; ++i) { keep(dr[i]); keep(xr[i]); }
+#pragma unroll
+        for (int i = 0; i < SB; ++i) {
+            S[(w * SB + i) * LDD + lane] = dr[i];
+            xr[i] = (w * SB + i) < rows ? xr[i] : T(0);
+        }
+    }
     __syncthreads();
 
     const int fm = lane & 15, fk = lane >> 4;            // MFMA operand lane -> (m|n, k)
     int bad = 0;
 #define NSGP_SUBPANEL(C0)                                                                             \
     {                                                                                                 \
-        if (w == 0) { const int bd = factor_subpanel<T, C0>(S, lane); if (bad == 0) bad = bd; }       \
-        __syncthreads();                                                                              \
         constexpr int B0 = C0 / SB;                                                                   \
+        if (w == 0) { const int bd = factor_subpanel<T, C0>(S, rd, lane); if (bad == 0) bad = bd; }   \
+        else if (w == 1 && B0 > 0) invert_subblock<T>(S, rd, Dinv, B0 - 1, lane);  /* overlaps the factor */ \
+        __syncthreads();                                                                              \
         constexpr int NT = (3 - B0) * (4 - B0) / 2;      /* lower tiles of the trailing block */      \
         for (int q = w; q < NT; q += 4) {                                                             \
             int ti = B0 + 1, tj = B0 + 1, c = q;                                                      \
@@ -266,20 +287,7 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(T* __restrict__ A, int
     NSGP_SUBPANEL(48)
 #undef NSGP_SUBPANEL
 
-    // inverse of diagonal sub-block w: lane c < 16 builds column c by forward substitution
-    if (lane < SB) {
-        const T* Lw = S + (w * SB) * LDD + w * SB;
-        T x[SB];
-#pragma unroll
-        for (int i = 0; i < SB; ++i) {
-            T acc = lane == i ? T(1) : T(0);
-#pragma unroll
-            for (int k = 0; k < i; ++k) acc -= Lw[i * LDD + k] * x[k];
-            x[i] = i < lane ? T(0) : acc / Lw[i * LDD + i];
-        }
-#pragma unroll
-        for (int i = 0; i < SB; ++i) Dinv[(w * SB + i) * LDI + lane] = x[i];
-    }
+    if (w == 1) invert_subblock<T>(S, rd, Dinv, 3, lane);
 #pragma unroll
     for (int i = 0; i < SB; ++i) Xs[(w * SB + i) * LDD + lane] = xr[i];
     __syncthreads();
@@ -328,7 +336,89 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(T* __restrict__ A, int
         if (w * SB + i < rows) Ab[(r0 + w * SB + i) * lda + j0 + lane] = Xw[i * LDD + lane];
 }
 
-// LAST, ragged panel (nb < 64, nothing below it): block 0 factors it in LDS, block 1 writes back panel j-1.
+// Rank-64 trailing update  C -= L21 L21^T  on the lower 64x64 tiles of a (rows x wcols) region, one tile per
+// workgroup, ONE K step: both operand blocks and the C tile are requested up front (a single memory
+// latency), then 16 MFMA k-steps per 16x16 tile.  The generic GEMM pays a load latency per BK=16 K-tile
+// (13 us for this shape); this kernel takes ~5 us, which matters because it sits on the serial panel chain.
+template <typename T>
+__global__ __launch_bounds__(256) void potrf_syrk64_kernel(T* __restrict__ A, int64_t n, int64_t lda, int64_t sA,
+                                                           int64_t j0, int64_t wcols) {
+    typedef Mma16<T> MM;
+    typedef typename MM::acc_t acc_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char panel_smem[];
+    T* As = reinterpret_cast<T*>(panel_smem);           // [64][LDD]  L21 rows of the tile's row block
+    T* Bs = As + NB * LDD;                              // [64][LDD]  L21 rows of the tile's column block
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int fm = lane & 15, fk = lane >> 4;
+    T* Ab = A + (int64_t)blockIdx.y * sA;
+    const int64_t base = j0 + NB;                       // first row / column of the trailing block
+    const int64_t tn = (wcols + NB - 1) / NB;           // tile columns
+    // compact enumeration of the lower tiles: rows 0..tn-1 form a triangle, the rest are full
+    const int64_t lin = blockIdx.x, tri = tn * (tn + 1) / 2;
+    int64_t ti, tj;
+    if (lin < tri) {
+        int64_t r = (int64_t)((sqrtf(8.0f * (float)lin + 1.0f) - 1.0f) * 0.5f);
+        while (r * (r + 1) / 2 > lin) --r;
+        while ((r + 1) * (r + 2) / 2 <= lin) ++r;
+        ti = r; tj = lin - r * (r + 1) / 2;
+    } else {
+        const int64_t q = lin - tri;
+        ti = tn + q / tn; tj = q % tn;
+    }
+    const int64_t r0 = base + ti * NB, c0 = base + tj * NB;
+    const int64_t clim = base + wcols < n ? base + wcols : n;
+    // C tile straight into the accumulator layout: wave w owns rows [16w, 16w+16), 4 column tiles.
+    // Every global load of the kernel is issued before anything waits (clamped indices, masks applied later).
+    acc_t acc[4];
+    T ar[SB], br[SB];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = r0 + w * SB + MM::crow(r, lane), col = c0 + t * SB + fm;
+            acc[t][r] = Ab[(row < n ? row : n - 1) * lda + (col < clim ? col : clim - 1)];
+        }
+#pragma unroll
+    for (int i = 0; i < SB; ++i) {
+        const int64_t ra = r0 + w * SB + i, rb = c0 + w * SB + i;
+        ar[i] = Ab[(ra < n ? ra : n - 1) * lda + j0 + lane];
+        br[i] = Ab[(rb < n ? rb : n - 1) * lda + j0 + lane];          // == ar[i] on diagonal tiles (L2 hit)
+    }
+#pragma unroll
+    for (int i = 0; i < SB; ++i) { keep(ar[i]); keep(br[i]); }
+#pragma unroll
+    for (int i = 0; i < SB; ++i) {
+        const int64_t ra = r0 + w * SB + i, rb = c0 + w * SB + i;
+        As[(w * SB + i) * LDD + lane] = ra < n ? ar[i] : T(0);
+        Bs[(w * SB + i) * LDD + lane] = rb < n ? br[i] : T(0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            T v = acc[t][r];
+            keep(v);
+            const int64_t row = r0 + w * SB + MM::crow(r, lane), col = c0 + t * SB + fm;
+            acc[t][r] = (row < n && col < clim) ? v : T(0);
+        }
+    __syncthreads();
+    const T* Bq = Bs;
+#pragma unroll
+    for (int kk = 0; kk < NB / 4; ++kk) {
+        const T av = -As[(w * SB + fm) * LDD + 4 * kk + fk];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = MM::mma(av, Bq[(t * SB + fm) * LDD + 4 * kk + fk], acc[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = r0 + w * SB + MM::crow(r, lane), col = c0 + t * SB + fm;
+            if (row < n && col < clim) Ab[row * lda + col] = acc[t][r];
+        }
+}
+
+// LAST, ragged panel (nb < 64, nothing below it), factored in LDS by one wave.
 template <typename T>
 __global__ __launch_bounds__(64) void potrf_tail_kernel(T* __restrict__ A, int64_t n, int64_t lda, int64_t sA,
                                                         int64_t j0, T* __restrict__ wsL, int64_t npanels,
@@ -338,10 +428,6 @@ __global__ __launch_bounds__(64) void potrf_tail_kernel(T* __restrict__ A, int64
     const int64_t b = blockIdx.y;
     T* Ab = A + b * sA;
     const int64_t pj = j0 / NB;
-    if (blockIdx.x == 1) {
-        if (pj > 0) writeback_panel(Ab, n, lda, wsL + (b * npanels + pj - 1) * NB * NB, pj - 1, lane);
-        return;
-    }
     const int nb = (int)(n - j0);
     if (lane < nb)
         for (int j = 0; j <= lane; ++j) Ls[lane * LDD + j] = Ab[(j0 + lane) * lda + j0 + j];
@@ -352,12 +438,24 @@ __global__ __launch_bounds__(64) void potrf_tail_kernel(T* __restrict__ A, int64
     if (lane == 0 && bad && info[b] == 0) info[b] = (int32_t)(j0 + bad);
 }
 
-// final write-back of the last panel
+// Finalisation: one workgroup per 64x64 tile on or above the diagonal.  Diagonal tiles receive their factor
+// from the side buffer (strict upper part zeroed), tiles above the diagonal are zeroed (L is lower).
 template <typename T>
-__global__ __launch_bounds__(64) void potrf_writeback_kernel(T* __restrict__ A, int64_t n, int64_t lda, int64_t sA,
+__global__ __launch_bounds__(256) void potrf_finalize_kernel(T* __restrict__ A, int64_t n, int64_t lda, int64_t sA,
                                                              const T* __restrict__ wsL, int64_t npanels) {
-    const int64_t b = blockIdx.y;
-    writeback_panel(A + b * sA, n, lda, wsL + (b * npanels + npanels - 1) * NB * NB, npanels - 1, (int)threadIdx.x);
+    const int64_t ti = blockIdx.y, tj = blockIdx.x, b = blockIdx.z;
+    if (tj < ti) return;
+    T* Ab = A + b * sA;
+    const int64_t r0 = ti * NB, c0 = tj * NB;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t c = c0 + lane;
+    if (c >= n) return;
+    const T* src = wsL + (b * npanels + ti) * NB * NB;
+    for (int i = w; i < NB; i += 4) {
+        const int64_t r = r0 + i;
+        if (r >= n) break;
+        Ab[r * lda + c] = (tj == ti && lane <= i) ? src[i * NB + lane] : T(0);
+    }
 }
 
 template <typename T>
@@ -374,35 +472,54 @@ int potrf_impl(T* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int32_t*
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(info, 0, sizeof(int32_t) * batch, st);
     if (e != hipSuccess) return (int)e;
-    const size_t panel_lds = (2 * (size_t)NB * LDD + 4 * SB * LDI) * sizeof(T);
-    static bool attr_set = false;       // idempotent attribute, set once per process and type
+    const size_t panel_lds = (2 * (size_t)NB * LDD + 4 * SB * LDI + NB) * sizeof(T);
+    const size_t syrk_lds = 2 * (size_t)NB * LDD * sizeof(T);
+    static bool attr_set = false;       // idempotent attributes, set once per process and type
     if (!attr_set) {
         if (panel_lds > 65536)
             (void)hipFuncSetAttribute((const void*)potrf_panel_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)panel_lds);
+        if (syrk_lds > 65536)
+            (void)hipFuncSetAttribute((const void*)potrf_syrk64_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)syrk_lds);
         attr_set = true;
     }
-    for (int64_t j0 = 0; j0 < n; j0 += NB) {
-        const int64_t nb = (n - j0) < NB ? (n - j0) : NB;
-        if (nb < NB) {
-            hipLaunchKernelGGL((potrf_tail_kernel<T>), dim3(2, (unsigned)batch), dim3(64), 0, st, A, n, lda, sA, j0,
-                               wsL, npanels, info);
-            break;
+    // Two-level blocking for large matrices: rank-64 updates stay inside a 256-column outer panel (they are
+    // HBM-bound: 8 flop/B in float64), the rest of the trailing matrix is updated once per outer panel with
+    // K = 256.  Small matrices (the DSVI Kzz, n ~ 1024) are latency-bound and use one level.
+    const int64_t NB2 = n >= 2048 ? 4 * NB : n;
+    for (int64_t J0 = 0; J0 < n; J0 += NB2) {
+        const int64_t Jend = (J0 + NB2) < n ? (J0 + NB2) : n;
+        for (int64_t j0 = J0; j0 < Jend; j0 += NB) {
+            const int64_t nb = (n - j0) < NB ? (n - j0) : NB;
+            if (nb < NB) {
+                hipLaunchKernelGGL((potrf_tail_kernel<T>), dim3(1, (unsigned)batch), dim3(64), 0, st, A, n, lda, sA,
+                                   j0, wsL, npanels, info);
+                break;
+            }
+            const int64_t below = n - j0 - nb;
+            const int64_t nslab = below > 0 ? cdiv64(below, NB) : 1;
+            hipLaunchKernelGGL((potrf_panel_kernel<T>), dim3((unsigned)nslab, (unsigned)batch), dim3(256), panel_lds,
+                               st, A, n, lda, sA, j0, wsL, npanels, info);
+            const int64_t wcols = Jend - (j0 + nb);               // columns of this outer panel still to update
+            if (below > 0 && wcols > 0) {
+                const int64_t tm = cdiv64(below, NB), tn = cdiv64(wcols, NB);
+                const int64_t ntile = tn * (tn + 1) / 2 + (tm - tn) * tn;
+                hipLaunchKernelGGL((potrf_syrk64_kernel<T>), dim3((unsigned)ntile, (unsigned)batch), dim3(256),
+                                   syrk_lds, st, A, n, lda, sA, j0, wcols);
+            }
         }
-        const int64_t below = n - j0 - nb;
-        const int64_t nslab = below > 0 ? cdiv64(below, NB) : 1;
-        hipLaunchKernelGGL((potrf_panel_kernel<T>), dim3((unsigned)(nslab + 1), (unsigned)batch), dim3(256),
-                           panel_lds, st, A, n, lda, sA, j0, wsL, npanels, info);
-        if (below > 0) {
-            T* L21 = A + (j0 + nb) * lda + j0;
-            T* A22 = A + (j0 + nb) * lda + (j0 + nb);
-            int rc = gemm_t<T>(below, below, nb, T(-1), L21, lda, 1, sA, 0, L21, 1, lda, sA, 0, T(1), A22, lda, sA, 0,
+        if (Jend < n) {
+            const int64_t rest = n - Jend, kw = Jend - J0;
+            T* Lp = A + Jend * lda + J0;
+            T* A22 = A + Jend * lda + Jend;
+            int rc = gemm_t<T>(rest, rest, kw, T(-1), Lp, lda, 1, sA, 0, Lp, 1, lda, sA, 0, T(1), A22, lda, sA, 0,
                                batch, 1, NSGP_GEMM_C_LOWER, stream);
             if (rc) return rc;
         }
     }
-    hipLaunchKernelGGL((potrf_writeback_kernel<T>), dim3(1, (unsigned)batch), dim3(64), 0, st, A, n, lda, sA,
-                       (const T*)wsL, npanels);
+    hipLaunchKernelGGL((potrf_finalize_kernel<T>), dim3((unsigned)npanels, (unsigned)npanels, (unsigned)batch),
+                       dim3(256), 0, st, A, n, lda, sA, (const T*)wsL, npanels);
     return nsgp_launch_status();
 }
 
