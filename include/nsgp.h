@@ -181,6 +181,44 @@ int nsgp_svgp_colstats_bwd_f64(const double* A, const double* C, const double* m
                                const double* gmean, const double* gvar, int64_t batch, int64_t M, int64_t n,
                                double* Abar, double* C2, double* mbar, void* stream);
 
+/* K6, fused form used by the DSVI step (the stand-alone colstats kernels above remain for callers that
+ * already hold A and C).  The two projections of VariationalStrategy.forward, A = L^-1 Kzx (as W Kzx with
+ * W = L^-1 lower) and C = Lq^T A, run as triangular MFMA GEMMs whose EPILOGUE also reduces the column
+ * statistics of the tile, so A and C are never re-read:
+ *   tri_gemm_colstats: Y[b] = L[b] X[b] (trans = 0, L lower) or L[b]^T X[b] (trans = 1); X, Y (batch,M,n)
+ *       part_dot[b,t,j] = sum_{k in row tile t} Y[b,k,j] rowvec[b,k]     (skipped when part_dot == NULL)
+ *       part_sq [b,t,j] = sum_{k in row tile t} Y[b,k,j]^2
+ *       with t < T = nsgp_svgp_colstats_tiles(M, n, batch, elem_size); partial buffers are (batch,T,n).
+ *   colstats_finalize: mean = sum_t part_dot;  var = base + sum_t (part_sq_c - part_sq_a).
+ * Backward (hand-derived adjoints, nsgp/svgp.py):
+ *   abar : Abar = 2 (Lq C) diag(gvar) + m gmean^T - 2 A diag(gvar)        one GEMM, fused epilogue
+ *   lqbar: Lqbar = tril(A diag(2 gvar) C^T)          one GEMM, operand scaled on its way into LDS
+ *   rowdot: out[b,k] = sum_j A[b,k,j] g[b,j]         (mbar = A gmean) */
+size_t nsgp_svgp_colstats_tiles(int64_t M, int64_t n, int64_t batch, int elem_size);
+int nsgp_svgp_tri_gemm_colstats_f32(const float* L, int trans, const float* X, const float* rowvec, int64_t batch,
+                                    int64_t M, int64_t n, float* Y, float* part_dot, float* part_sq, void* stream);
+int nsgp_svgp_tri_gemm_colstats_f64(const double* L, int trans, const double* X, const double* rowvec, int64_t batch,
+                                    int64_t M, int64_t n, double* Y, double* part_dot, double* part_sq,
+                                    void* stream);
+int nsgp_svgp_colstats_finalize_f32(const float* part_dot, const float* part_sq_a, const float* part_sq_c,
+                                    const float* base, int64_t batch, int64_t tiles, int64_t n, float* mean,
+                                    float* var, void* stream);
+int nsgp_svgp_colstats_finalize_f64(const double* part_dot, const double* part_sq_a, const double* part_sq_c,
+                                    const double* base, int64_t batch, int64_t tiles, int64_t n, double* mean,
+                                    double* var, void* stream);
+int nsgp_svgp_abar_f32(const float* Lq, const float* C, const float* A, const float* m, const float* gmean,
+                       const float* gvar, int64_t batch, int64_t M, int64_t n, float* Abar, void* stream);
+int nsgp_svgp_abar_f64(const double* Lq, const double* C, const double* A, const double* m, const double* gmean,
+                       const double* gvar, int64_t batch, int64_t M, int64_t n, double* Abar, void* stream);
+size_t nsgp_svgp_lqbar_workspace(int64_t batch, int64_t M, int64_t n, int elem_size);
+int nsgp_svgp_lqbar_f32(const float* A, const float* C, const float* gvar, int64_t batch, int64_t M, int64_t n,
+                        float* Lqbar, void* ws, size_t ws_bytes, void* stream);
+int nsgp_svgp_lqbar_f64(const double* A, const double* C, const double* gvar, int64_t batch, int64_t M, int64_t n,
+                        double* Lqbar, void* ws, size_t ws_bytes, void* stream);
+int nsgp_rowdot_f32(const float* A, const float* g, int64_t batch, int64_t M, int64_t n, float* out, void* stream);
+int nsgp_rowdot_f64(const double* A, const double* g, int64_t batch, int64_t M, int64_t n, double* out,
+                    void* stream);
+
 /* DeepGPLayer sampling:  h[s,i,c] = mean[c,s?,i] + sqrt(var[c,s?,i]) * eps[s,i,c]
  *   mean/var are (b, ns, n) with ns == 1 (deterministic first layer, broadcast over S) or ns == S.
  *   backward accumulates gmean/gvar (b, ns, n) from gh (S,n,b). */

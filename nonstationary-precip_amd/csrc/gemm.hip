@@ -58,6 +58,21 @@ struct GemmArgs {
     int modeA, modeB;             // 0: contiguous along k, 1: contiguous along m (n)
 };
 
+// Fused epilogues / loader hooks of the SVGP projection GEMMs (kind 0 = plain GEMM).
+//   kind 1 (column statistics): C = alpha*acc as usual, plus per-tile-row partial column sums
+//          p0[bb][bm][col] = sum_{rows of tile bm} C[row][col] * rv[bb][row]   (skipped when p0 == null)
+//          p1[bb][bm][col] = sum_{rows of tile bm} C[row][col]^2
+//   kind 2 (SVGP A-adjoint): C[row][col] = alpha*acc * 2 cs[col] + rv[row] * gc[col] - 2 cs[col] * mat[row][col]
+//          (mat has C's layout; cs, gc: (batch, N); rv: (batch, M))
+//   ks != null: the B operand is scaled along k on its way into LDS, B'(k, n) = ks[bb][k] * B(k, n).
+struct Epi {
+    int kind;
+    const void *rv, *cs, *gc, *mat, *ks;
+    void *p0, *p1;
+    int modeA, modeB;       // operand modes of the instantiated variant (any strides are valid in either mode;
+                            // the mode only decides the vector-load direction)
+};
+
 // 4-element register fragment loaded from global
 template <typename T> struct Frag4 { T v[4]; };
 
@@ -111,10 +126,10 @@ __device__ __forceinline__ Frag4<T> load_operand4(const T* base, int64_t sr, int
 }
 
 // MODE_A / MODE_B: 0 = operand contiguous along k, 1 = contiguous along m (n).
-template <typename T, int BM, int BN, int BK, int MODE_A, int MODE_B>
+template <typename T, int BM, int BN, int BK, int MODE_A, int MODE_B, int EPI = 0, int KSC = 0>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g, T alpha, const T* __restrict__ A,
                                                    const T* __restrict__ B, T beta, T* __restrict__ C,
-                                                   T* __restrict__ slabs) {
+                                                   T* __restrict__ slabs, Epi ep) {
     using MF = Mfma<T>;
     constexpr int MT = MF::MT, KS = MF::KS, NKK = BK / KS;
     constexpr int KCH = NKK < 8 ? NKK : 8;                      // k-steps whose fragments are prefetched together
@@ -221,6 +236,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g, T alpha, const
     const int64_t stepA = MODE_A == 0 ? 1 : g.sak, stepB = MODE_B == 0 ? 1 : g.sbk;
 
     Frag4<T> ra[PA], rb[PB];
+    Frag4<T> rks[KSC ? PB : 1];
+    const T* ksb = KSC ? reinterpret_cast<const T*>(ep.ks) + bb * g.K : nullptr;
+    const bool ks_vec = KSC && ((uintptr_t)ksb % (4 * sizeof(T)) == 0);
 
     auto gload = [&](int64_t k0) {
         const bool kfull = k0 + BK <= kend;
@@ -242,6 +260,24 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g, T alpha, const
             for (int p = 0; p < PB; ++p)   // B(k,n): "lower" zero where n > k <=> k < r ; "upper" zero where k > r
                 rb[p] = load_operand4<T>(Bb, g.sbn, g.sbk, n0 + br[p], k0 + bk[p], g.N, kend, MODE_B, g.vecB, bU, bL);
         }
+        if constexpr (KSC != 0) {
+#pragma unroll
+            for (int p = 0; p < PB; ++p) {
+                const int64_t k = k0 + bk[p];
+                if (MODE_B == 0) {
+                    if (ks_vec && k + 3 < kend) {
+                        rks[p] = ldg4(ksb + k);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) rks[p].v[e] = k + e < kend ? ksb[k + e] : T(0);
+                    }
+                } else {
+                    const T v = k < kend ? ksb[k] : T(0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rks[p].v[e] = v;
+                }
+            }
+        }
     };
     auto sstore = [&](int buf) {
 #pragma unroll
@@ -253,6 +289,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g, T alpha, const
 #pragma unroll
                 for (int e = 0; e < 4; ++e) As[buf][ak[p] * LDA + ar[p] + e] = ra[p].v[e];
             }
+        }
+        if constexpr (KSC != 0) {
+#pragma unroll
+            for (int p = 0; p < PB; ++p)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rb[p].v[e] *= rks[p].v[e];
         }
 #pragma unroll
         for (int p = 0; p < PB; ++p) {
@@ -300,6 +342,91 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g, T alpha, const
     }
 
     // epilogue
+    if constexpr (EPI == 1) {
+        // plain store + per-column partial sums over this tile's rows (rows >= M carry acc == 0)
+        const T* rv = ep.rv ? reinterpret_cast<const T*>(ep.rv) + bb * g.M : nullptr;
+        T sdot[TN], ssq[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { sdot[j] = T(0); ssq[j] = T(0); }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < MF::NREG; ++r) {
+                const int64_t row = m0 + wm0 + i * MT + MF::crow(r, lane);
+                const T rvv = (rv && row < g.M) ? rv[row] : T(0);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int64_t col = n0 + wn0 + j * MT + MF::ccol(lane);
+                    const T v = alpha * acc[i][j][r];
+                    if (row < g.M && col < g.N) Cb[row * g.ldc + col] = v;
+                    sdot[j] += v * rvv;
+                    ssq[j] += v * v;
+                }
+            }
+        // lanes that share a column (f32: lane ^ 32; f64: lane ^ 16, lane ^ 32), then the two waves along m
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int off = MT; off < 64; off <<= 1) {
+                sdot[j] += __shfl_xor(sdot[j], off);
+                ssq[j] += __shfl_xor(ssq[j], off);
+            }
+        }
+        T* red = reinterpret_cast<T*>(gemm_smem);               // [2 quantities][2 waves along m][BN]
+        __syncthreads();
+        if (lane < MT) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int c = wn0 + j * MT + lane;
+                red[(0 + (wave >> 1)) * BN + c] = sdot[j];
+                red[(2 + (wave >> 1)) * BN + c] = ssq[j];
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < g.N) {
+            const int64_t o = (bb * g.tiles_m + bm) * g.N + n0 + tid;
+            if (ep.p0) reinterpret_cast<T*>(ep.p0)[o] = red[tid] + red[BN + tid];
+            reinterpret_cast<T*>(ep.p1)[o] = red[2 * BN + tid] + red[3 * BN + tid];
+        }
+        return;
+    } else if constexpr (EPI == 2) {
+        const T* mat = reinterpret_cast<const T*>(ep.mat) + b1 * g.sc1 + b2 * g.sc2;
+        const T* rv = reinterpret_cast<const T*>(ep.rv) + bb * g.M;
+        const T* gc = reinterpret_cast<const T*>(ep.gc) + bb * g.N;
+        const T* cs = reinterpret_cast<const T*>(ep.cs) + bb * g.N;
+        const bool inside = (m0 + BM <= g.M) && (n0 + BN <= g.N);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int64_t col = n0 + wn0 + j * MT + MF::ccol(lane);
+            const int64_t colc = col < g.N ? col : g.N - 1;
+            const T gcol = gc[colc], c2 = T(2) * cs[colc];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                T av[MF::NREG], rvv[MF::NREG];
+                if (inside) {
+#pragma unroll
+                    for (int r = 0; r < MF::NREG; ++r) {
+                        const int64_t row = m0 + wm0 + i * MT + MF::crow(r, lane);
+                        av[r] = mat[row * g.ldc + col];
+                        rvv[r] = rv[row];
+                    }
+#pragma unroll
+                    for (int r = 0; r < MF::NREG; ++r) {
+                        const int64_t row = m0 + wm0 + i * MT + MF::crow(r, lane);
+                        Cb[row * g.ldc + col] = (alpha * acc[i][j][r] - av[r]) * c2 + rvv[r] * gcol;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < MF::NREG; ++r) {
+                        const int64_t row = m0 + wm0 + i * MT + MF::crow(r, lane);
+                        if (row < g.M && col < g.N)
+                            Cb[row * g.ldc + col] = (alpha * acc[i][j][r] - mat[row * g.ldc + col]) * c2 + rv[row] * gcol;
+                    }
+                }
+            }
+        }
+        return;
+    }
     const bool to_slab = g.ksplit > 1;
     T* out = to_slab ? slabs + slice * g.slab + bb * g.M * g.N : Cb;
     const int64_t ldo = to_slab ? g.N : g.ldc;
@@ -386,7 +513,6 @@ template <typename T> Plan make_plan(int64_t M, int64_t N, int64_t K, int64_t nb
         const double cost = (double)rounds * ((double)cdiv64(ktiles, ks) + 6.0) + (ks > 1 ? 2.0 * ks / 4.0 : 0.0);
         if (cost < best_cost - 1e-9) { best_cost = cost; best_ks = ks; }
     }
-    { const char* e = getenv("NSGP_GEMM_KSPLIT"); if (e && can_split) best_ks = atoi(e); }
     p.kper = cdiv64(cdiv64(K, best_ks), 32) * 32;
     if (p.kper < 32) p.kper = 32;
     p.ksplit = cdiv64(K, p.kper);
@@ -398,7 +524,7 @@ template <typename T>
 int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam, int64_t sak, int64_t sa1,
               int64_t sa2, const T* B, int64_t sbk, int64_t sbn, int64_t sb1, int64_t sb2, T beta, T* C,
               int64_t ldc, int64_t sc1, int64_t sc2, int64_t nb1, int64_t nb2, int flags, void* ws, size_t wsb,
-              void* stream) {
+              void* stream, const Epi* epi = nullptr, int64_t* tiles_m_out = nullptr) {
     if (M < 0) return -1; if (N < 0) return -2; if (K < 0) return -3;
     if (nb1 < 1 || nb2 < 1) return -20;
     if (M == 0 || N == 0) return 0;
@@ -415,6 +541,7 @@ int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam,
     g.ksplit = p.ksplit; g.kper = p.kper; g.slab = nb * M * N; g.flags = flags;
     g.modeA = (sak == 1) ? 0 : (sam == 1 ? 1 : 0);
     g.modeB = (sbk == 1) ? 0 : (sbn == 1 ? 1 : 0);
+    if (epi && (epi->kind != 0 || epi->ks)) { g.modeA = epi->modeA; g.modeB = epi->modeB; }
     const size_t al = 4 * sizeof(T);
     auto vec_ok = [&](const void* ptr, int64_t unit, int64_t other, int64_t s1, int64_t s2) {
         return unit == 1 && other % 4 == 0 && s1 % 4 == 0 && s2 % 4 == 0 && ((uintptr_t)ptr % al) == 0;
@@ -444,6 +571,40 @@ int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam,
             }
     }
     dim3 grid((unsigned)ngrid, (unsigned)(nb * g.ksplit), 1);
+    Epi ep{};
+    if (epi) ep = *epi;
+    if (tiles_m_out) *tiles_m_out = g.tiles_m;
+    const int ekind = ep.kind, eks = ep.ks != nullptr;
+    if (ekind != 0 && (g.ksplit != 1 || beta != T(0) || (flags & NSGP_GEMM_C_LOWER))) return -30;
+#define NSGP_LAUNCH_X(BMN, MA, MB, EP, KS)                                                                \
+    do {                                                                                                  \
+        constexpr int BKc = (BMN == 128 ? 32 : 16);                                                       \
+        constexpr int pa = (MA == 0 && sizeof(T) == 4) ? 1 : Mfma<T>::PAD;                                \
+        constexpr int pb = (MB == 0 && sizeof(T) == 4) ? 1 : Mfma<T>::PAD;                                \
+        constexpr size_t lds = 2 * BKc * ((BMN + pa) + (BMN + pb)) * sizeof(T);                           \
+        auto kern = gemm_kernel<T, BMN, BMN, BKc, MA, MB, EP, KS>;                                        \
+        static bool attr_done = false;                                                                    \
+        if (!attr_done && lds > 65536) {                                                                  \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        }                                                                                                 \
+        attr_done = true;                                                                                 \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g, alpha, A, B, beta, C, slabs, ep);           \
+    } while (0)
+#define NSGP_LAUNCH_EPI(BMN)                                                                              \
+    do {                                                                                                  \
+        if (ekind == 1 && !eks && g.modeA == 0 && g.modeB == 1) NSGP_LAUNCH_X(BMN, 0, 1, 1, 0);           \
+        else if (ekind == 1 && !eks && g.modeA == 1 && g.modeB == 1) NSGP_LAUNCH_X(BMN, 1, 1, 1, 0);      \
+        else if (ekind == 2 && !eks && g.modeA == 0 && g.modeB == 1) NSGP_LAUNCH_X(BMN, 0, 1, 2, 0);      \
+        else if (ekind == 0 && eks && g.modeA == 0 && g.modeB == 0) NSGP_LAUNCH_X(BMN, 0, 0, 0, 1);       \
+        else return -31;                                                                                  \
+    } while (0)
+    if (ekind != 0 || eks) {
+        if (p.big) {
+            if constexpr (sizeof(T) == 4) NSGP_LAUNCH_EPI(128);
+        } else {
+            NSGP_LAUNCH_EPI(64);
+        }
+    } else {
 #define NSGP_LAUNCH(BMN, MA, MB)                                                                          \
     do {                                                                                                  \
         constexpr int BKc = (BMN == 128 ? 32 : 16);                                                       \
@@ -456,7 +617,7 @@ int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam,
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         }                                                                                                 \
         attr_done = true;                                                                                 \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g, alpha, A, B, beta, C, slabs);               \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g, alpha, A, B, beta, C, slabs, ep);           \
     } while (0)
 #define NSGP_LAUNCH_MODES(BMN)                                                 \
     do {                                                                       \
@@ -472,6 +633,9 @@ int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam,
     }
 #undef NSGP_LAUNCH_MODES
 #undef NSGP_LAUNCH
+    }
+#undef NSGP_LAUNCH_EPI
+#undef NSGP_LAUNCH_X
     if (g.ksplit > 1) {
         const int64_t tot = nb * M * N;
         hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, st, g, alpha,
@@ -480,6 +644,45 @@ int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam,
     return nsgp_launch_status();
 }
 
+}  // namespace
+
+// ---- SVGP projection GEMMs with fused epilogues (include/nsgp.h, section K6) ---------------------------
+namespace {
+template <typename T>
+int tri_gemm_colstats_impl(const T* L, int trans, const T* X, const T* rowvec, int64_t batch, int64_t M, int64_t n,
+                           T* Y, T* part_dot, T* part_sq, void* stream) {
+    if (!L) return -1; if (trans != 0 && trans != 1) return -2; if (!X) return -3;
+    if (batch < 0) return -5; if (M < 0) return -6; if (n < 0) return -7; if (!Y) return -8; if (!part_sq) return -10;
+    if (batch == 0 || M == 0 || n == 0) return 0;
+    Epi ep{};
+    ep.kind = 1; ep.rv = rowvec; ep.p0 = part_dot; ep.p1 = part_sq; ep.modeA = trans ? 1 : 0; ep.modeB = 1;
+    const int flags = (trans ? NSGP_GEMM_A_UPPER : NSGP_GEMM_A_LOWER) | NSGP_GEMM_NO_SPLITK;
+    return gemm_impl<T>(M, n, M, T(1), L, trans ? 1 : M, trans ? M : 1, M * M, 0, X, n, 1, M * n, 0, T(0), Y, n, M * n, 0,
+                        batch, 1, flags, nullptr, 0, stream, &ep);
+}
+template <typename T>
+int abar_impl(const T* Lq, const T* C, const T* A, const T* m, const T* gmean, const T* gvar, int64_t batch, int64_t M,
+              int64_t n, T* Abar, void* stream) {
+    if (!Lq) return -1; if (!C) return -2; if (!A) return -3; if (!m) return -4; if (!gmean) return -5; if (!gvar) return -6;
+    if (batch < 0) return -7; if (M < 0) return -8; if (n < 0) return -9; if (!Abar) return -10;
+    if (batch == 0 || M == 0 || n == 0) return 0;
+    Epi ep{};
+    ep.kind = 2; ep.rv = m; ep.cs = gvar; ep.gc = gmean; ep.mat = A; ep.modeA = 0; ep.modeB = 1;
+    return gemm_impl<T>(M, n, M, T(1), Lq, M, 1, M * M, 0, C, n, 1, M * n, 0, T(0), Abar, n, M * n, 0, batch, 1,
+                        NSGP_GEMM_A_LOWER | NSGP_GEMM_NO_SPLITK, nullptr, 0, stream, &ep);
+}
+template <typename T>
+int lqbar_impl(const T* A, const T* C, const T* gvar, int64_t batch, int64_t M, int64_t n, T* Lqbar, void* ws,
+               size_t wsb, void* stream) {
+    if (!A) return -1; if (!C) return -2; if (!gvar) return -3;
+    if (batch < 0) return -4; if (M < 0) return -5; if (n < 0) return -6; if (!Lqbar) return -7;
+    if (batch == 0 || M == 0) return 0;
+    Epi ep{};
+    ep.kind = 0; ep.ks = gvar; ep.modeA = 0; ep.modeB = 0;
+    // Lqbar = tril(A diag(2 gvar) C^T):  B(k, j) = C[j][k], scaled along k by gvar, alpha = 2
+    return gemm_impl<T>(M, M, n, T(2), A, n, 1, M * n, 0, C, 1, n, M * n, 0, T(0), Lqbar, M, M * M, 0, batch, 1,
+                        NSGP_GEMM_C_LOWER, ws, wsb, stream, &ep);
+}
 }  // namespace
 
 extern "C" {
@@ -504,6 +707,42 @@ int nsgp_gemm_f64(int64_t M, int64_t N, int64_t K, double alpha, const double* A
                   int flags, void* ws, size_t wsb, void* stream) {
     return gemm_impl<double>(M, N, K, alpha, A, sam, sak, sa1, sa2, B, sbk, sbn, sb1, sb2, beta, C, ldc, sc1, sc2,
                              nb1, nb2, flags, ws, wsb, stream);
+}
+
+
+size_t nsgp_svgp_colstats_tiles(int64_t M, int64_t n, int64_t batch, int elem_size) {
+    if (M <= 0 || n <= 0 || batch <= 0) return 0;
+    const int flags = NSGP_GEMM_A_LOWER | NSGP_GEMM_NO_SPLITK;
+    const Plan p = elem_size == 4 ? make_plan<float>(M, n, M, batch, flags) : make_plan<double>(M, n, M, batch, flags);
+    return (size_t)cdiv64(M, p.big ? 128 : 64);
+}
+int nsgp_svgp_tri_gemm_colstats_f32(const float* L, int trans, const float* X, const float* rowvec, int64_t batch,
+                                    int64_t M, int64_t n, float* Y, float* part_dot, float* part_sq, void* stream) {
+    return tri_gemm_colstats_impl<float>(L, trans, X, rowvec, batch, M, n, Y, part_dot, part_sq, stream);
+}
+int nsgp_svgp_tri_gemm_colstats_f64(const double* L, int trans, const double* X, const double* rowvec, int64_t batch,
+                                    int64_t M, int64_t n, double* Y, double* part_dot, double* part_sq,
+                                    void* stream) {
+    return tri_gemm_colstats_impl<double>(L, trans, X, rowvec, batch, M, n, Y, part_dot, part_sq, stream);
+}
+int nsgp_svgp_abar_f32(const float* Lq, const float* C, const float* A, const float* m, const float* gmean,
+                       const float* gvar, int64_t batch, int64_t M, int64_t n, float* Abar, void* stream) {
+    return abar_impl<float>(Lq, C, A, m, gmean, gvar, batch, M, n, Abar, stream);
+}
+int nsgp_svgp_abar_f64(const double* Lq, const double* C, const double* A, const double* m, const double* gmean,
+                       const double* gvar, int64_t batch, int64_t M, int64_t n, double* Abar, void* stream) {
+    return abar_impl<double>(Lq, C, A, m, gmean, gvar, batch, M, n, Abar, stream);
+}
+size_t nsgp_svgp_lqbar_workspace(int64_t batch, int64_t M, int64_t n, int elem_size) {
+    return nsgp_gemm_workspace(M, M, n, batch, 1, elem_size, NSGP_GEMM_C_LOWER);
+}
+int nsgp_svgp_lqbar_f32(const float* A, const float* C, const float* gvar, int64_t batch, int64_t M, int64_t n,
+                        float* Lqbar, void* ws, size_t ws_bytes, void* stream) {
+    return lqbar_impl<float>(A, C, gvar, batch, M, n, Lqbar, ws, ws_bytes, stream);
+}
+int nsgp_svgp_lqbar_f64(const double* A, const double* C, const double* gvar, int64_t batch, int64_t M, int64_t n,
+                        double* Lqbar, void* ws, size_t ws_bytes, void* stream) {
+    return lqbar_impl<double>(A, C, gvar, batch, M, n, Lqbar, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -41,6 +41,53 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ A, 
     }
 }
 
+// ---- colstats from the GEMM epilogues' per-tile-row partial sums ----------------------------------
+template <typename T>
+__global__ void colstats_finalize_kernel(const T* __restrict__ pdot, const T* __restrict__ psqA,
+                                         const T* __restrict__ psqC, const T* __restrict__ base, int64_t batch,
+                                         int64_t tiles, int64_t n, T* __restrict__ mean, T* __restrict__ var) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= batch * n) return;
+    const int64_t b = idx / n, j = idx % n;
+    T sm = T(0), sa = T(0), sc = T(0);
+    for (int64_t t = 0; t < tiles; ++t) {
+        const int64_t o = (b * tiles + t) * n + j;
+        sm += pdot[o]; sa += psqA[o]; sc += psqC[o];
+    }
+    mean[idx] = sm;
+    var[idx] = base[b] + (sc - sa);
+}
+
+// ---- out[b][i] = sum_j A[b][i][j] * g[b][j]  (one workgroup per row; the m-gradient  A gmean) ------
+template <typename T>
+__global__ __launch_bounds__(256) void rowdot_kernel(const T* __restrict__ A, const T* __restrict__ g, int64_t M,
+                                                     int64_t n, T* __restrict__ out) {
+    __shared__ T lds[4];
+    const int64_t b = blockIdx.y, i = blockIdx.x;
+    const T* row = A + (b * M + i) * n;
+    const T* gb = g + b * n;
+    T acc = T(0);
+    constexpr int V = 16 / sizeof(T);
+    const bool vec = (n % V == 0) && ((uintptr_t)row % 16 == 0) && ((uintptr_t)gb % 16 == 0);
+    if (vec) {
+        for (int64_t j = (int64_t)threadIdx.x * V; j < n; j += 256 * V) {
+            if constexpr (sizeof(T) == 4) {
+                const float4 a = *reinterpret_cast<const float4*>(row + j);
+                const float4 q = *reinterpret_cast<const float4*>(gb + j);
+                acc += a.x * q.x + a.y * q.y + a.z * q.z + a.w * q.w;
+            } else {
+                const double2 a = *reinterpret_cast<const double2*>(row + j);
+                const double2 q = *reinterpret_cast<const double2*>(gb + j);
+                acc += a.x * q.x + a.y * q.y;
+            }
+        }
+    } else {
+        for (int64_t j = threadIdx.x; j < n; j += 256) acc += row[j] * gb[j];
+    }
+    acc = block_sum_256(acc, lds);
+    if (threadIdx.x == 0) out[b * M + i] = acc;
+}
+
 // ---- colstats backward: one block per (row k, batch b) ------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void colstats_bwd_kernel(const T* __restrict__ A, const T* __restrict__ C,
@@ -377,6 +424,45 @@ int nsgp_kl_whitened_fwd_f64(const double* m, const double* Lq, int64_t batch, i
 int nsgp_kl_whitened_bwd_f64(const double* m, const double* Lq, int64_t batch, int64_t M, double gout, double* gm,
                              double* gLq, void* stream) {
     return kl_bwd_impl<double>(m, Lq, batch, M, gout, gm, gLq, stream);
+}
+
+
+int nsgp_svgp_colstats_finalize_f32(const float* part_dot, const float* part_sq_a, const float* part_sq_c,
+                                    const float* base, int64_t batch, int64_t tiles, int64_t n, float* mean,
+                                    float* var, void* stream) {
+    if (!part_dot) return -1; if (!part_sq_a) return -2; if (!part_sq_c) return -3; if (!base) return -4;
+    if (batch < 0) return -5; if (tiles < 0) return -6; if (n < 0) return -7; if (!mean) return -8; if (!var) return -9;
+    if (batch * n == 0) return 0;
+    hipLaunchKernelGGL((colstats_finalize_kernel<float>), dim3((unsigned)cdiv64(batch * n, 256)), dim3(256), 0,
+                       (hipStream_t)stream, part_dot, part_sq_a, part_sq_c, base, batch, tiles, n, mean, var);
+    return nsgp_launch_status();
+}
+int nsgp_svgp_colstats_finalize_f64(const double* part_dot, const double* part_sq_a, const double* part_sq_c,
+                                    const double* base, int64_t batch, int64_t tiles, int64_t n, double* mean,
+                                    double* var, void* stream) {
+    if (!part_dot) return -1; if (!part_sq_a) return -2; if (!part_sq_c) return -3; if (!base) return -4;
+    if (batch < 0) return -5; if (tiles < 0) return -6; if (n < 0) return -7; if (!mean) return -8; if (!var) return -9;
+    if (batch * n == 0) return 0;
+    hipLaunchKernelGGL((colstats_finalize_kernel<double>), dim3((unsigned)cdiv64(batch * n, 256)), dim3(256), 0,
+                       (hipStream_t)stream, part_dot, part_sq_a, part_sq_c, base, batch, tiles, n, mean, var);
+    return nsgp_launch_status();
+}
+int nsgp_rowdot_f32(const float* A, const float* g, int64_t batch, int64_t M, int64_t n, float* out, void* stream) {
+    if (!A) return -1; if (!g) return -2; if (batch < 0) return -3; if (M < 0) return -4; if (n < 0) return -5;
+    if (!out) return -6;
+    if (batch * M == 0) return 0;
+    hipLaunchKernelGGL((rowdot_kernel<float>), dim3((unsigned)M, (unsigned)batch), dim3(256), 0, (hipStream_t)stream,
+                       A, g, M, n, out);
+    return nsgp_launch_status();
+}
+int nsgp_rowdot_f64(const double* A, const double* g, int64_t batch, int64_t M, int64_t n, double* out,
+                    void* stream) {
+    if (!A) return -1; if (!g) return -2; if (batch < 0) return -3; if (M < 0) return -4; if (n < 0) return -5;
+    if (!out) return -6;
+    if (batch * M == 0) return 0;
+    hipLaunchKernelGGL((rowdot_kernel<double>), dim3((unsigned)M, (unsigned)batch), dim3(256), 0, (hipStream_t)stream,
+                       A, g, M, n, out);
+    return nsgp_launch_status();
 }
 
 }  // extern "C"

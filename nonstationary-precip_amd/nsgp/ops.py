@@ -374,6 +374,64 @@ def svgp_colstats_bwd(A, C, m, gmean, gvar):
     return Abar, C2, mbar
 
 
+def _timed(launch, flops, dtype):
+    if _gemm_timer is not None:
+        _gemm_timer(launch, flops, dtype)
+    else:
+        launch()
+
+
+def svgp_project(W, Kzx, Lq, m, base):
+    """Fused K6 forward: A = W Kzx, C = Lq^T A (triangular MFMA GEMMs) with the column statistics reduced in
+    the GEMM epilogues.  W, Lq:(b,M,M) lower; Kzx:(b,M,n); m:(b,M); base:(b,).
+    Returns A, C, mean = A^T m, var = base + colsum(C^2 - A^2)."""
+    ref = _chk(W, Kzx, Lq, m, base)
+    W, Kzx, Lq, m, base = _c(W), _c(Kzx), _c(Lq), _c(m), _c(base.reshape(-1))
+    batch, M, n = Kzx.shape
+    if W.shape != (batch, M, M) or Lq.shape != (batch, M, M) or m.shape != (batch, M) or base.shape != (batch,):
+        raise BackendError('svgp_project: shapes')
+    lib = _lib.load()
+    T = int(lib.nsgp_svgp_colstats_tiles(M, n, batch, ref.element_size()))
+    A, C = torch.empty_like(Kzx), torch.empty_like(Kzx)
+    part = torch.empty((3, batch, max(T, 1), n), dtype=ref.dtype, device=ref.device)
+    mean = torch.empty((batch, n), dtype=ref.dtype, device=ref.device)
+    var = torch.empty_like(mean)
+    sfx, st = _sfx(ref), _stream()
+    flops = 1.0 * M * M * n * batch                      # 2 M M n / 2 (triangular operand)
+    _timed(lambda: _lib.call(f'nsgp_svgp_tri_gemm_colstats_{sfx}', _p(W), 0, _p(Kzx), _p(m), batch, M, n, _p(A),
+                             _p(part[0]), _p(part[1]), st), flops, ref.dtype)
+    _timed(lambda: _lib.call(f'nsgp_svgp_tri_gemm_colstats_{sfx}', _p(Lq), 1, _p(A), None, batch, M, n, _p(C),
+                             None, _p(part[2]), st), flops, ref.dtype)
+    _lib.call(f'nsgp_svgp_colstats_finalize_{sfx}', _p(part[0]), _p(part[1]), _p(part[2]), _p(base), batch, T, n,
+              _p(mean), _p(var), st)
+    return A, C, mean, var
+
+
+def svgp_project_bwd(Lq, m, A, C, gmean, gvar):
+    """Adjoints of svgp_project w.r.t. A (total, through C as well), Lq and m:
+    Abar = 2 (Lq C) diag(gvar) + m gmean^T - 2 A diag(gvar);  Lqbar = tril(A diag(2 gvar) C^T);  mbar = A gmean."""
+    ref = _chk(Lq, m, A, C, gmean, gvar)
+    Lq, m, A, C, gmean, gvar = _c(Lq), _c(m), _c(A), _c(C), _c(gmean), _c(gvar)
+    batch, M, n = A.shape
+    if C.shape != A.shape or Lq.shape != (batch, M, M) or m.shape != (batch, M) or gmean.shape != (batch, n) \
+            or gvar.shape != (batch, n):
+        raise BackendError('svgp_project_bwd: shapes')
+    lib = _lib.load()
+    sfx, st = _sfx(ref), _stream()
+    Abar = torch.empty_like(A)
+    Lqbar = torch.empty_like(Lq)
+    mbar = torch.empty_like(m)
+    flops = 1.0 * M * M * n * batch
+    _lib.call(f'nsgp_rowdot_{sfx}', _p(A), _p(gmean), batch, M, n, _p(mbar), st)
+    _timed(lambda: _lib.call(f'nsgp_svgp_abar_{sfx}', _p(Lq), _p(C), _p(A), _p(m), _p(gmean), _p(gvar), batch, M, n,
+                             _p(Abar), st), flops, ref.dtype)
+    wsb = lib.nsgp_svgp_lqbar_workspace(batch, M, n, ref.element_size())
+    ws = _ws(wsb, ref.device) if wsb else None
+    _timed(lambda: _lib.call(f'nsgp_svgp_lqbar_{sfx}', _p(A), _p(C), _p(gvar), batch, M, n, _p(Lqbar), _p(ws),
+                             ws.numel() if ws is not None else 0, st), flops, ref.dtype)
+    return Abar, Lqbar, mbar
+
+
 def dgp_sample(mean, var, eps):
     """h[s,i,c] = mean[c,s',i] + sqrt(var[c,s',i]) eps[s,i,c]; mean/var:(b,ns,n) ns in {1,S}; eps:(S,n,b)."""
     ref = _chk(mean, var, eps)

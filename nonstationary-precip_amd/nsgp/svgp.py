@@ -11,8 +11,9 @@ MI355X formulation (same math, no per-sample redundancy, everything on the matri
                                     for every layer of the model in one batched chain (WhitenFn)
     A   = W Kzx                     f32 MFMA GEMM, lower-triangular W skips half the K-tiles
     C   = Lq^T A                    f32 MFMA GEMM, upper-triangular operand
-    var = base + colsum(C o C) - colsum(A o A)
-The backward is 4 more (M x M x n) GEMMs per layer (SVGPLayerFn) + one batched M^3 Cholesky adjoint
+    var = base + colsum(C o C) - colsum(A o A)      reduced in the two GEMMs' epilogues (A, C not re-read)
+The backward is 4 more (M x M x n) GEMMs per layer (SVGPLayerFn; the elementwise parts of Abar / Lqbar are
+folded into a GEMM epilogue and an operand loader) + one batched M^3 Cholesky adjoint
 (WhitenFn); every identity is checked against torch autograd of the oracle in tests/test_gpu_svgp.py.
 """
 import torch
@@ -108,9 +109,7 @@ class SVGPLayerFn(torch.autograd.Function):
     def forward(ctx, x, Z, ls, os_, m, Lq, W64):
         W = ops.cast(W64, x.dtype)
         Kzx = ops.rbf_build(Z, x, ls, os_)                                       # (b,M,n)
-        A = ops.gemm(W, Kzx, flags=GEMM_A_LOWER)
-        C = ops.gemm(Lq, A, ta=True, flags=GEMM_A_UPPER)
-        mean, var = ops.svgp_colstats(A, C, m, os_ + VAR_JITTER)
+        A, C, mean, var = ops.svgp_project(W, Kzx, Lq, m, os_ + VAR_JITTER)      # 2 GEMMs, stats in the epilogues
         ctx.save_for_backward(x, Z, ls, os_, m, Lq, W, Kzx, A, C)
         ctx.w_dtype = W64.dtype
         return mean, var
@@ -118,10 +117,7 @@ class SVGPLayerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gmean, gvar):
         x, Z, ls, os_, m, Lq, W, Kzx, A, C = ctx.saved_tensors
-        gmean, gvar = gmean.contiguous(), gvar.contiguous()
-        Abar, C2, mbar = ops.svgp_colstats_bwd(A, C, m, gmean, gvar)
-        ops.gemm(Lq, C2, flags=GEMM_A_LOWER, beta=1.0, out=Abar)                # Abar += Lq C2
-        Lqbar = ops.gemm(A, C2, tb=True, flags=GEMM_C_LOWER)                     # tril(A C2^T)
+        Abar, Lqbar, mbar = ops.svgp_project_bwd(Lq, m, A, C, gmean.contiguous(), gvar.contiguous())
         Kzxbar = ops.gemm(W, Abar, ta=True, flags=GEMM_A_UPPER)                  # W^T Abar
         Wbar = ops.gemm(Abar, Kzx, tb=True, flags=GEMM_C_LOWER)                  # tril(Abar Kzx^T)
         need_x = ctx.needs_input_grad[0]

@@ -81,3 +81,44 @@ def test_svgp_layer_at_init_is_the_prior():
     mean, var, _ = svgp_marginal(x, Z, ls, os_, m, Lq)
     assert float(mean.abs().max()) == 0.0
     assert torch.allclose(var, (os_ + 1e-4)[:, None].expand(b, n), atol=2e-5)
+
+
+@pytest.mark.parametrize('dt', [F64, F32])
+@pytest.mark.parametrize('b,M,n', [(1, 1, 1), (2, 63, 65), (1, 130, 700), (3, 256, 1000), (1, 1024, 4096)])
+def test_fused_projection_ops_match_dense_formulas(dt, b, M, n):
+    """nsgp_svgp_tri_gemm_colstats / colstats_finalize / abar / lqbar / rowdot (the GEMMs with fused epilogues
+    behind SVGPLayerFn) against the dense float64 formulas they restate, ragged and tile-aligned sizes."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from nsgp import ops
+    g = _g(1000 + M + n)
+    W = torch.tril(torch.randn(b, M, M, generator=g, dtype=F64)) / max(M, 1) ** 0.5
+    Lq = torch.tril(0.3 * torch.randn(b, M, M, generator=g, dtype=F64)) + torch.eye(M, dtype=F64)
+    K = torch.randn(b, M, n, generator=g, dtype=F64)
+    m = torch.randn(b, M, generator=g, dtype=F64)
+    base = torch.rand(b, generator=g, dtype=F64) + 0.5
+    gm = torch.randn(b, n, generator=g, dtype=F64)
+    gv = torch.randn(b, n, generator=g, dtype=F64)
+    dev = lambda t: t.to(dt).cuda()
+    # garbage in the strict upper triangles must be ignored (only the lower triangles are operands)
+    junk = torch.triu(torch.full((M, M), 7.0, dtype=F64), 1)
+    A, C, mean, var = ops.svgp_project(dev(W + junk), dev(K), dev(Lq + junk), dev(m), dev(base))
+    A_ref = W @ K
+    C_ref = Lq.transpose(-1, -2) @ A_ref
+    mean_ref = torch.einsum('bkj,bk->bj', A_ref, m)
+    var_ref = base[:, None] + (C_ref ** 2).sum(1) - (A_ref ** 2).sum(1)
+    tol = dict(rtol=1e-10, atol=1e-10) if dt == F64 else dict(rtol=2e-4, atol=2e-4 * max(1.0, M ** 0.5))
+    assert torch.allclose(A.cpu().double(), A_ref, **tol)
+    assert torch.allclose(C.cpu().double(), C_ref, **tol)
+    assert torch.allclose(mean.cpu().double(), mean_ref, **tol)
+    assert torch.allclose(var.cpu().double(), var_ref, **tol)
+    Abar, Lqbar, mbar = ops.svgp_project_bwd(dev(Lq + junk), dev(m), A, C, dev(gm), dev(gv))
+    A_, C_ = A.cpu().double(), C.cpu().double()           # adjoints evaluated at the device's own A, C
+    Abar_ref = 2 * (Lq @ C_) * gv[:, None, :] + m[:, :, None] * gm[:, None, :] - 2 * A_ * gv[:, None, :]
+    Lqbar_ref = torch.tril(torch.einsum('bkj,bj,blj->bkl', A_, 2 * gv, C_))
+    mbar_ref = torch.einsum('bkj,bj->bk', A_, gm)
+    tolb = dict(rtol=1e-9, atol=1e-9) if dt == F64 else dict(rtol=5e-4, atol=5e-4 * max(1.0, (n * 1.0) ** 0.5))
+    assert torch.allclose(Abar.cpu().double(), Abar_ref, **(tol if dt == F64 else tolb))
+    assert torch.allclose(Lqbar.cpu().double(), Lqbar_ref, **tolb)
+    assert torch.allclose(mbar.cpu().double(), mbar_ref, **tolb)
+    assert float(torch.triu(Lqbar, 1).abs().max()) == 0.0 if M > 1 else True
