@@ -28,7 +28,8 @@ class Interval(torch.nn.Module):
     def transform(self, raw):
         lb, ub = float(self.lower_bound), float(self.upper_bound)
         if math.isinf(ub):
-            return torch.nn.functional.softplus(raw) + lb
+            sp = torch.nn.functional.softplus(raw)
+            return sp if lb == 0.0 else sp + lb               # Positive: no extra elementwise launch
         return torch.sigmoid(raw) * (ub - lb) + lb
 
     def inverse_transform(self, value):

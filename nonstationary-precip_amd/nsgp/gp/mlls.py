@@ -64,17 +64,22 @@ class _ApproximateMarginalLogLikelihood(MarginalLogLikelihood):
         num_batch = approximate_dist_f.event_shape[0]
         log_likelihood = self._log_likelihood_term(approximate_dist_f, target, num_batch=num_batch, **kwargs)
         kl_divergence = self.model.variational_strategy.kl_divergence() / (self.num_data / self.beta)
-        added_loss = torch.zeros_like(log_likelihood)
-        had_added = False
+        added_loss, log_prior = None, None                 # absent terms cost no launches
         for term in self.model.added_loss_terms():
-            added_loss = added_loss + term.loss()
-            had_added = True
-        log_prior = torch.zeros_like(log_likelihood)
+            added_loss = term.loss() if added_loss is None else added_loss + term.loss()
         for _, module, prior, closure, _ in self.named_priors():
-            log_prior = log_prior + prior.log_prob(closure(module)).sum() / self.num_data
+            lp = prior.log_prob(closure(module)).sum() / self.num_data
+            log_prior = lp if log_prior is None else log_prior + lp
         if self.combine_terms:
-            return log_likelihood - kl_divergence + log_prior - added_loss
-        if had_added:
+            res = log_likelihood - kl_divergence
+            if log_prior is not None:
+                res = res + log_prior
+            if added_loss is not None:
+                res = res - added_loss
+            return res
+        if log_prior is None:
+            log_prior = torch.zeros_like(log_likelihood)
+        if added_loss is not None:
             return log_likelihood, kl_divergence, log_prior, added_loss
         return log_likelihood, kl_divergence, log_prior
 

@@ -8,7 +8,7 @@ from . import settings
 from .distributions import MultivariateNormal, MultitaskMultivariateNormal
 from .lazy import delazify
 from .likelihoods import GaussianLikelihood
-from .module import Module
+from .module import Module, transform_cache
 
 
 class GP(Module):
@@ -164,7 +164,12 @@ class _DeepGPVariationalStrategy(object):
 
     def kl_divergence(self):
         # tied layers are one module -> counted once
-        return sum(s.kl_divergence().sum() for s in self.sub_variational_strategies)
+        total = None
+        for s in self.sub_variational_strategies:
+            kl = s.kl_divergence()
+            kl = kl.reshape(()) if kl.numel() == 1 else kl.sum()
+            total = kl if total is None else total + kl
+        return total if total is not None else 0.0
 
 
 class DeepGP(GP):
@@ -183,22 +188,23 @@ class DeepGP(GP):
         strategies = [s for s in self.variational_strategy.sub_variational_strategies
                       if hasattr(s, 'whiten_group')]
         shared = False
-        if len(strategies) > 1 and len({s.inducing_points.shape[-2] for s in strategies}) == 1 \
-                and args and torch.is_tensor(args[0]) and args[0].is_cuda:
-            for s in strategies:
-                s._maybe_init()
-            groups = [s.whiten_group() for s in strategies]
-            Ws, _info = whiten(groups, settings.variational_cholesky_jitter.value(args[0].dtype),
-                               settings.chol_bwd_f64.on())
-            for s, W in zip(strategies, Ws):
-                s._W64_shared = W
-            shared = True
-        try:
-            return super().__call__(*args, **kwargs)
-        finally:
-            if shared:
+        with transform_cache():
+            if len(strategies) > 1 and len({s.inducing_points.shape[-2] for s in strategies}) == 1 \
+                    and args and torch.is_tensor(args[0]) and args[0].is_cuda:
                 for s in strategies:
-                    s._W64_shared = None
+                    s._maybe_init()
+                groups = [s.whiten_group() for s in strategies]
+                Ws, _info = whiten(groups, settings.variational_cholesky_jitter.value(args[0].dtype),
+                                   settings.chol_bwd_f64.on())
+                for s, W in zip(strategies, Ws):
+                    s._W64_shared = W
+                shared = True
+            try:
+                return super().__call__(*args, **kwargs)
+            finally:
+                if shared:
+                    for s in strategies:
+                        s._W64_shared = None
 
 
 class DeepLikelihood(GaussianLikelihood):

@@ -11,6 +11,22 @@ from torch import nn
 from .constraints import Interval
 
 
+# Scoped cache of constrained parameter values: inside `transform_cache()` every softplus(raw) is computed once
+# per (parameter, version) instead of once per property access (a DSVI step reads each lengthscale /
+# outputscale three times).  The scope ends with the forward pass, so no autograd graph outlives its backward.
+_transform_cache = []
+
+
+class transform_cache:
+    def __enter__(self):
+        _transform_cache.append(_transform_cache[-1] if _transform_cache else {})   # nested scopes share
+        return self
+
+    def __exit__(self, *exc):
+        _transform_cache.pop()
+        return False
+
+
 class Module(nn.Module):
     def __init__(self):
         super().__init__()
@@ -69,7 +85,16 @@ class Module(nn.Module):
     def _get_constrained(self, raw_name):
         p = self._parameters[raw_name]
         c = self.constraint_for_parameter_name(raw_name)
-        return c.transform(p) if c is not None else p
+        if c is None:
+            return p
+        cache = _transform_cache[-1] if _transform_cache else None
+        if cache is None:
+            return c.transform(p)
+        key = (id(p), p._version, torch.is_grad_enabled())
+        val = cache.get(key)
+        if val is None:
+            val = cache[key] = c.transform(p)
+        return val
 
     # ---- priors -----------------------------------------------------------------------------
     def register_prior(self, name, prior, param_or_closure, setting_closure=None):
