@@ -78,7 +78,7 @@ def build(device, dp_world):
     torch.manual_seed(SEED)
     model = dgps.DeepGP(1, (N_DATA, 3), num_inducing=M_INDUCING).to(device)
     mll = DeepApproximateMLL(VariationalELBO(model.likelihood, model, N_DATA))
-    opt = FusedAdam(model.parameters(), lr=0.01, capturable=True)
+    opt = FusedAdam(model.parameters(), lr=0.01, capturable=True, grads_as_views=False)
     return model, mll, opt
 
 
@@ -220,11 +220,15 @@ def main():
         out = model(x_in)
         loss = -dp_objective(mll, out, y_in, BATCH, world)
         loss.backward()
+        opt.bucket.gather_grads()            # one multi-tensor copy into the flat gradient bucket
         return loss.detach()
+
+    def adam_step():
+        opt.step(gather=False)
 
     def whole_step():
         loss = fwd_bwd()
-        opt.step()
+        adam_step()
         return loss
 
     def barrier():
@@ -241,19 +245,19 @@ def main():
                 g_step = GraphedCallable(whole_step)                 # forward + ELBO + backward + Adam: one graph
             else:
                 g_fb = GraphedCallable(fwd_bwd)                      # all-reduce stays an eager RCCL call
-                g_adam = GraphedCallable(opt.step, warmup=1)
+                g_adam = GraphedCallable(adam_step, warmup=1)
 
         def step(k):
             x_in.copy_(xs[k % n_batches]); y_in.copy_(ys[k % n_batches])
             if not use_graph:
                 loss = fwd_bwd()
-                dp.allreduce_grads()
-                opt.step()
+                dp.allreduce_grads(gather=False)
+                adam_step()
             elif world == 1:
                 loss = g_step()
             else:
                 loss = g_fb()
-                dp.allreduce_grads()
+                dp.allreduce_grads(gather=False)
                 g_adam()
             return loss
 
@@ -279,8 +283,8 @@ def main():
         for k in range(nprof):
             x_in.copy_(xs[k % n_batches]); y_in.copy_(ys[k % n_batches])
             fwd_bwd()
-            dp.allreduce_grads()
-            opt.step()
+            dp.allreduce_grads(gather=False)
+            adam_step()
         gemm_ms, gemm_flops, gemm_launches = timer.summary(torch.float32)
         g64_ms, g64_flops, g64_launches = timer.summary(torch.float64)
         ops.set_gemm_timer(None)

@@ -261,20 +261,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g, T alpha, const
                 rb[p] = load_operand4<T>(Bb, g.sbn, g.sbk, n0 + br[p], k0 + bk[p], g.N, kend, MODE_B, g.vecB, bU, bL);
         }
         if constexpr (KSC != 0) {
-#pragma unroll
-            for (int p = 0; p < PB; ++p) {
-                const int64_t k = k0 + bk[p];
-                if (MODE_B == 0) {
-                    if (ks_vec && k + 3 < kend) {
-                        rks[p] = ldg4(ksb + k);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) rks[p].v[e] = k + e < kend ? ksb[k + e] : T(0);
-                    }
+            if (MODE_B == 0) {
+                // every fragment of this thread covers the same 4 k's (bk[p] does not depend on p): ONE load
+                const int64_t k = k0 + bk[0];
+                if (ks_vec && k + 3 < kend) {
+                    rks[0] = ldg4(ksb + k);
                 } else {
-                    const T v = k < kend ? ksb[k] : T(0);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) rks[p].v[e] = v;
+                    for (int e = 0; e < 4; ++e) rks[0].v[e] = k + e < kend ? ksb[k + e] : T(0);
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < PB; ++p) {
+                    const int64_t k = k0 + bk[p];
+                    rks[p].v[0] = k < kend ? ksb[k] : T(0);
                 }
             }
         }
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g, T alpha, const
 #pragma unroll
             for (int p = 0; p < PB; ++p)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) rb[p].v[e] *= rks[p].v[e];
+                for (int e = 0; e < 4; ++e) rb[p].v[e] *= (MODE_B == 0 ? rks[0].v[e] : rks[p].v[0]);
         }
 #pragma unroll
         for (int p = 0; p < PB; ++p) {
@@ -491,15 +491,16 @@ static inline int64_t active_tiles(int64_t M, int64_t N, int64_t bm, int flags) 
 // (2 for the 128x128 f32 tile, 6 / 3 for the 64x64 f32 / f64 tiles); the number of rounds the grid needs
 // is ceil(active_blocks / slots), so the K-split is chosen to minimise rounds x K-tiles per block plus
 // the slab traffic of the split (measured: 792 active blocks on 512 slots ran 905 us, CUs 55 % busy).
-template <typename T> Plan make_plan(int64_t M, int64_t N, int64_t K, int64_t nb, int flags) {
+template <typename T> Plan make_plan(int64_t M, int64_t N, int64_t K, int64_t nb, int flags, bool allow_big = true) {
     Plan p;
     const bool can_split = !(flags & NSGP_GEMM_NO_SPLITK) && K >= 512;
     int64_t maxks = can_split ? K / 256 : 1;
     if (maxks > 64) maxks = 64;
     if (maxks < 1) maxks = 1;
     const int64_t tiles_big = active_tiles(M, N, 128, flags) * nb;
-    // 128x128 tiles (f32 only) when, with K-splitting, they still fill the 256 CUs
-    p.big = sizeof(T) == 4 && tiles_big * maxks >= 256;
+    // 128x128 tiles (f32 only) when, with K-splitting, they still fill the 256 CUs.  (A 128x128x16 float64
+    // tile was tried: 256 VGPRs + 132 AGPRs, one wave per SIMD -- 3 x 1024^3 went from 0.40 to 0.59 ms.)
+    p.big = allow_big && sizeof(T) == 4 && tiles_big * maxks >= 256;
     const int64_t bm = p.big ? 128 : 64;
     const int64_t tiles = active_tiles(M, N, bm, flags) * nb;
     const int64_t slots = 256 * (p.big ? 2 : (sizeof(T) == 4 ? 6 : 3));
@@ -532,7 +533,8 @@ int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam,
     if ((flags & NSGP_GEMM_A_LOWER) && (flags & NSGP_GEMM_A_UPPER)) return -22;
     if ((flags & NSGP_GEMM_B_LOWER) && (flags & NSGP_GEMM_B_UPPER)) return -22;
     const int64_t nb = nb1 * nb2;
-    Plan p = make_plan<T>(M, N, K, nb, flags);
+    const bool has_epi = epi && (epi->kind != 0 || epi->ks);
+    Plan p = make_plan<T>(M, N, K, nb, flags, !(has_epi && sizeof(T) == 8));   // fused variants: f64 on 64-tiles only
     GemmArgs g;
     g.M = M; g.N = N; g.K = K;
     g.sam = sam; g.sak = sak; g.sa1 = sa1; g.sa2 = sa2;
@@ -607,7 +609,7 @@ int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam,
     } else {
 #define NSGP_LAUNCH(BMN, MA, MB)                                                                          \
     do {                                                                                                  \
-        constexpr int BKc = (BMN == 128 ? 32 : 16);                                                       \
+        constexpr int BKc = (BMN == 128 && sizeof(T) == 4 ? 32 : 16);                                                     \
         constexpr int pa = (MA == 0 && sizeof(T) == 4) ? 1 : Mfma<T>::PAD;                                \
         constexpr int pb = (MB == 0 && sizeof(T) == 4) ? 1 : Mfma<T>::PAD;                                \
         constexpr size_t lds = 2 * BKc * ((BMN + pa) + (BMN + pb)) * sizeof(T);                           \
@@ -713,7 +715,8 @@ int nsgp_gemm_f64(int64_t M, int64_t N, int64_t K, double alpha, const double* A
 size_t nsgp_svgp_colstats_tiles(int64_t M, int64_t n, int64_t batch, int elem_size) {
     if (M <= 0 || n <= 0 || batch <= 0) return 0;
     const int flags = NSGP_GEMM_A_LOWER | NSGP_GEMM_NO_SPLITK;
-    const Plan p = elem_size == 4 ? make_plan<float>(M, n, M, batch, flags) : make_plan<double>(M, n, M, batch, flags);
+    const Plan p = elem_size == 4 ? make_plan<float>(M, n, M, batch, flags)
+                                  : make_plan<double>(M, n, M, batch, flags, false);
     return (size_t)cdiv64(M, p.big ? 128 : 64);
 }
 int nsgp_svgp_tri_gemm_colstats_f32(const float* L, int trans, const float* X, const float* rowvec, int64_t batch,
@@ -734,7 +737,10 @@ int nsgp_svgp_abar_f64(const double* Lq, const double* C, const double* A, const
     return abar_impl<double>(Lq, C, A, m, gmean, gvar, batch, M, n, Abar, stream);
 }
 size_t nsgp_svgp_lqbar_workspace(int64_t batch, int64_t M, int64_t n, int elem_size) {
-    return nsgp_gemm_workspace(M, M, n, batch, 1, elem_size, NSGP_GEMM_C_LOWER);
+    if (M <= 0 || n <= 0 || batch <= 0) return 0;
+    const Plan p = elem_size == 4 ? make_plan<float>(M, M, n, batch, NSGP_GEMM_C_LOWER)
+                                  : make_plan<double>(M, M, n, batch, NSGP_GEMM_C_LOWER, false);
+    return p.ksplit > 1 ? (size_t)p.ksplit * batch * M * M * elem_size : 0;
 }
 int nsgp_svgp_lqbar_f32(const float* A, const float* C, const float* gvar, int64_t batch, int64_t M, int64_t n,
                         float* Lqbar, void* ws, size_t ws_bytes, void* stream) {

@@ -5,15 +5,18 @@
 // ExactMarginalLogLikelihood / MultivariateNormal.log_prob and torch.triangular_solve(eye, chol)
 // (models/gibbs_kernels.py:203,300).
 //
-// potrf, per 64-column panel j:
-//   panel kernel   every workgroup re-factors the 64x64 diagonal block in LDS (5 us, saves a launch
-//                  and a grid-wide dependency), inverts it in LDS and applies it to its own 64-row slab of
-//                  the panel:  L21 = A21 * L11^-T.  The factor goes to a side buffer (other
-//                  workgroups still read A11); one extra workgroup copies the PREVIOUS panel's
-//                  factor into place and zeroes the strict upper triangle of those rows.
-//   trailing       A22 -= L21 L21^T (lower tiles only) on the MFMA GEMM of gemm.hip.
-// trtri: invert the 64x64 diagonal blocks in LDS, then merge pairs of blocks bottom-up,
-//   X21 = -B^-1 (C A^-1), every level two batched MFMA GEMMs (log2(n/64) levels).
+// potrf, per 64-column panel j (right-looking):
+//   panel kernel   every workgroup (4 waves) re-factors the 64x64 diagonal block in LDS -- four 16-column
+//                  sub-panels, each factored by one wave in registers, the rest updated with 16x16x4 MFMAs --
+//                  inverts the 16x16 diagonal sub-blocks and solves its own 64-row slab of the panel
+//                  L21 = A21 L11^-T by blocked substitution on the MFMA.  The factor goes to a side buffer
+//                  (other workgroups still read A11); a final kernel copies the factors into place and
+//                  zeroes the strict upper triangle.
+//   trailing       rank-64 update of the lower tiles on a dedicated one-K-step kernel (all loads issued up
+//                  front); for n >= 2048 rank-64 updates stay inside a 256-column outer panel and the rest
+//                  of the trailing matrix is updated once per outer panel (K = 256) on the MFMA GEMM.
+// trtri: invert the 64x64 diagonal blocks (16x16 substitution + MFMA merges), then merge pairs of blocks
+//   bottom-up, X21 = -B^-1 (C A^-1), every level two batched MFMA GEMMs (log2(n/64) levels).
 #include "common.h"
 
 // from gemm.hip
@@ -48,10 +51,10 @@ template <> int gemm_t<double>(int64_t M, int64_t N, int64_t K, double alpha, co
                          nb2, flags | NSGP_GEMM_NO_SPLITK, nullptr, 0, stream);
 }
 
-// ---- wave-level 64x64 building blocks ------------------------------------------------------------
-// One wave owns a 64x64 block with ONE ROW PER LANE in registers (a[j] = element (lane, j)); values
-// of another row are broadcast with v_readlane (lane index is a compile-time constant after full
-// unrolling), so the whole factorisation is straight-line VALU code: no LDS, no barriers.
+// ---- wave-level building blocks --------------------------------------------------------------------
+// A wave holds ONE ROW PER LANE of a sub-panel in registers; values of another row are broadcast with
+// v_readlane (the lane index is a compile-time constant after full unrolling), so a 16-column sub-panel
+// factorisation is straight-line VALU code: no LDS traffic, no barriers.
 __device__ __forceinline__ float bcast(float v, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
@@ -73,40 +76,6 @@ __device__ __forceinline__ double fast_rsqrt(double a) {
     r = r * (1.5 - 0.5 * a * r * r);
     r = r * (1.5 - 0.5 * a * r * r);
     return r;
-}
-
-// In-register Cholesky of the block (right-looking by columns).  On exit a[j] (j <= lane) is L[lane][j],
-// a[j] (j > lane) is 0.  Returns 0 or the 1-based index of the first non-positive pivot (wave-uniform).
-template <typename T> __device__ __forceinline__ int factor_rows(T (&a)[NB], int lane) {
-    int bad = 0;
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
-        const T akk = bcast(a[k], k);
-        if (!(akk > T(0)) && bad == 0) bad = k + 1;
-        const T inv = fast_rsqrt(akk);                                     // NaN for akk <= 0, flagged above
-        const T piv = akk * inv;
-        const T lik = lane == k ? piv : (lane > k ? a[k] * inv : T(0));
-        a[k] = lik;
-#pragma unroll
-        for (int j = k + 1; j < NB; ++j) a[j] -= lik * bcast(lik, j);      // a[j] -= L[i][k] * L[j][k]
-    }
-    return bad;
-}
-
-// Column `lane` of X = L^-1 for the lower-triangular block whose row `lane` is a[]:  x[i] = X[i][lane].
-template <typename T> __device__ __forceinline__ void invert_rows(const T (&a)[NB], T (&x)[NB], int lane) {
-    // reciprocal of this lane's diagonal element L[lane][lane] (one division, off the serial chain)
-    T dg = T(1);
-#pragma unroll
-    for (int j = 0; j < NB; ++j) dg = (j == lane) ? a[j] : dg;
-    const T rd = T(1) / dg;
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        T acc = lane == i ? T(1) : T(0);
-#pragma unroll
-        for (int k = 0; k < i; ++k) acc -= bcast(a[k], i) * x[k];            // L[i][k] * X[k][lane]
-        x[i] = i < lane ? T(0) : acc * bcast(rd, i);                        // exact zeros above the diagonal
-    }
 }
 
 // Ragged tail (nb < 64): same algorithm with the block in LDS (lane i owns row i) and run-time loop
@@ -524,41 +493,105 @@ int potrf_impl(T* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int32_t*
 }
 
 // ---- trtri ---------------------------------------------------------------------------------
+// acc(16x16) += A(16xK) B(Kx16), operands in LDS: A[m * lda + k], B[k * ldb + n]  (K a multiple of 4)
 template <typename T>
-__global__ __launch_bounds__(64) void trtri_diag_kernel(const T* __restrict__ L, int64_t n, int64_t ldl, int64_t sL,
-                                                        T* __restrict__ X, int64_t ldx, int64_t sX) {
-    __shared__ T Ls[NB * LDD];
-    const int lane = threadIdx.x;
+__device__ __forceinline__ typename Mma16<T>::acc_t mm16(const T* A, int lda, const T* B, int ldb, int K,
+                                                         typename Mma16<T>::acc_t acc, int lane) {
+    const int fm = lane & 15, fk = lane >> 4;
+    for (int k = 0; k < K; k += 4) acc = Mma16<T>::mma(A[fm * lda + k + fk], B[(k + fk) * ldb + fm], acc);
+    return acc;
+}
+
+// Inverse of one 64x64 lower-triangular diagonal block per workgroup (4 waves): the four 16x16 diagonal
+// sub-blocks are inverted by forward substitution (one wave each), then merged bottom-up with 16x16x4 MFMAs,
+// X21 = -X22 (L21 X11), first into two 32x32 inverses, then into the 64x64 one.  A ragged last block is padded
+// with the identity.  Everything right of the block in its rows is zeroed (X is lower triangular).
+template <typename T>
+__global__ __launch_bounds__(256) void trtri_diag_kernel(const T* __restrict__ L, int64_t n, int64_t ldl, int64_t sL,
+                                                         T* __restrict__ X, int64_t ldx, int64_t sX) {
+    typedef Mma16<T> MM;
+    typedef typename MM::acc_t acc_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char panel_smem[];
+    T* S = reinterpret_cast<T*>(panel_smem);            // [64][LDD] L block
+    T* Xs = S + NB * LDD;                               // [64][LDD] inverse
+    T* Tm = Xs + NB * LDD;                              // [64][LDD] products L21 X11
+    T* Dinv = Tm + NB * LDD;                            // [4][16][LDI]
+    T* rd = Dinv + 4 * SB * LDI;                        // [64]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t b = blockIdx.y, r0 = (int64_t)blockIdx.x * NB;
     const T* Lb = L + b * sL;
     T* Xb = X + b * sX;
     const int nb = (int)((n - r0) < NB ? (n - r0) : NB);
-    if (nb == NB) {
-        // registers: lane holds row `lane` of L, produces column `lane` of the inverse
-        T a[NB], x[NB];
-#pragma unroll 16
-        for (int i = 0; i < NB; ++i) Ls[i * LDD + lane] = Lb[(r0 + i) * ldl + r0 + lane];      // coalesced rows
-        __syncthreads();
+    {
+        T lr[SB];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) a[j] = Ls[lane * LDD + j];
-        invert_rows(a, x, lane);
+        for (int i = 0; i < SB; ++i) {
+            const int64_t rr = r0 + w * SB + i, cc = r0 + lane;
+            lr[i] = Lb[(rr < n ? rr : n - 1) * ldl + (cc < n ? cc : n - 1)];
+        }
 #pragma unroll
-        for (int i = 0; i < NB; ++i) Xb[(r0 + i) * ldx + r0 + lane] = x[i];       // coalesced row stores
-    } else {
-        // ragged last block: column `lane` of the inverse by forward substitution through LDS
-        T* Xs = Ls;                          // Xs[k*LDD + c] = X[k][c]; L read straight from global (small)
-        if (lane < nb) {
-            for (int i = 0; i < nb; ++i) {
-                T acc = lane == i ? T(1) : T(0);
-                for (int k = lane; k < i; ++k) acc -= Lb[(r0 + i) * ldl + r0 + k] * Xs[k * LDD + lane];
-                acc = i < lane ? T(0) : acc / Lb[(r0 + i) * ldl + r0 + i];
-                Xs[i * LDD + lane] = acc;
-                Xb[(r0 + i) * ldx + r0 + lane] = acc;
-            }
+        for (int i = 0; i < SB; ++i) keep(lr[i]);
+#pragma unroll
+        for (int i = 0; i < SB; ++i) {
+            const int row = w * SB + i;
+            const bool in = row < nb && lane < nb;
+            S[row * LDD + lane] = in ? (lane <= row ? lr[i] : T(0)) : (row == lane ? T(1) : T(0));
+            Xs[row * LDD + lane] = T(0);
         }
     }
+    __syncthreads();
+    if (tid < NB) rd[tid] = T(1) / S[tid * LDD + tid];
+    __syncthreads();
+    invert_subblock<T>(S, rd, Dinv, w, lane);
+    __syncthreads();
+    {   // diagonal sub-blocks of X
+        const int i = lane >> 2, c0 = (lane & 3) * 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Xs[(w * SB + i) * LDD + w * SB + c0 + c] = Dinv[(w * SB + i) * LDI + c0 + c];
+    }
+    __syncthreads();
+    const int fm = lane & 15;
+    // level 1: 16 -> 32 (pairs (0,1) and (2,3); waves 0 and 1)
+    {
+        const int p = w, lo = 2 * p * SB, hi = lo + SB;
+        acc_t t = {T(0), T(0), T(0), T(0)};
+        if (w < 2) t = mm16<T>(S + hi * LDD + lo, LDD, Xs + lo * LDD + lo, LDD, SB, t, lane);
+        if (w < 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Tm[(hi + MM::crow(r, lane)) * LDD + lo + fm] = t[r];
+        }
+        __syncthreads();
+        acc_t x = {T(0), T(0), T(0), T(0)};
+        if (w < 2) x = mm16<T>(Xs + hi * LDD + hi, LDD, Tm + hi * LDD + lo, LDD, SB, x, lane);
+        __syncthreads();
+        if (w < 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Xs[(hi + MM::crow(r, lane)) * LDD + lo + fm] = -x[r];
+        }
+        __syncthreads();
+    }
+    // level 2: 32 -> 64; wave w owns tile (ti, tj) of the 32x32 block X[32:64, 0:32]
+    {
+        const int ti = w >> 1, tj = w & 1;
+        acc_t t = {T(0), T(0), T(0), T(0)};
+        t = mm16<T>(S + (32 + ti * SB) * LDD, LDD, Xs + tj * SB, LDD, 32, t, lane);            // L21 X11
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Tm[(32 + ti * SB + MM::crow(r, lane)) * LDD + tj * SB + fm] = t[r];
+        __syncthreads();
+        acc_t x = {T(0), T(0), T(0), T(0)};
+        x = mm16<T>(Xs + (32 + ti * SB) * LDD + 32, LDD, Tm + 32 * LDD + tj * SB, LDD, 32, x, lane);   // X22 T
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Xs[(32 + ti * SB + MM::crow(r, lane)) * LDD + tj * SB + fm] = -x[r];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < SB; ++i) {
+        const int row = w * SB + i;
+        if (row < nb && lane < nb) Xb[(r0 + row) * ldx + r0 + lane] = Xs[row * LDD + lane];
+    }
     // zero everything right of the diagonal block in these rows
-    for (int i = 0; i < nb; ++i)
+    for (int i = w; i < nb; i += 4)
         for (int64_t c = r0 + nb + lane; c < n; c += 64) Xb[(r0 + i) * ldx + c] = T(0);
 }
 
@@ -572,8 +605,16 @@ int trtri_impl(const T* L, int64_t n, int64_t ldl, int64_t sL, T* X, int64_t ldx
     if (n > NB && (!ws || wsb < need)) return -9;
     if (batch > 65535) return -8;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL((trtri_diag_kernel<T>), dim3((unsigned)cdiv64(n, NB), (unsigned)batch), dim3(64), 0, st, L, n,
-                       ldl, sL, X, ldx, sX);
+    const size_t diag_lds = (3 * (size_t)NB * LDD + 4 * SB * LDI + NB) * sizeof(T);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (diag_lds > 65536)
+            (void)hipFuncSetAttribute((const void*)trtri_diag_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)diag_lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((trtri_diag_kernel<T>), dim3((unsigned)cdiv64(n, NB), (unsigned)batch), dim3(256), diag_lds, st,
+                       L, n, ldl, sL, X, ldx, sX);
     T* Tm = (T*)ws;                      // (batch, n, n) scratch, same indexing as X with ld = n
     for (int64_t s = NB; s < n; s *= 2) {
         // pairs (A = X[i0:i0+s, i0:i0+s], B = X[i0+s:i0+s+h, ...], C = L[i0+s:i0+s+h, i0:i0+s])

@@ -65,7 +65,9 @@ class DataParallel:
         if self.world > 1:
             dist.broadcast(self.bucket.flat_p, src=src, group=self.group)
 
-    def allreduce_grads(self, async_op=False):
+    def allreduce_grads(self, async_op=False, gather=True):
+        if gather:
+            self.bucket.gather_grads()
         if self.world > 1:
             return dist.all_reduce(self.bucket.flat_g, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         return None

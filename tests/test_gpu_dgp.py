@@ -161,7 +161,8 @@ def test_predict_matches_oracle_and_full_covariance_is_consistent():
     assert torch.allclose(lp.cpu().double(), lp_ref, rtol=5e-3, atol=5e-2)
 
 
-def test_fused_adam_and_flat_bucket_train_the_dgp_like_torch_adam():
+@pytest.mark.parametrize('grads_as_views', [True, False])
+def test_fused_adam_and_flat_bucket_train_the_dgp_like_torch_adam(grads_as_views):
     _need_gpu()
     import copy
     from nsgp.gp.mlls import DeepApproximateMLL, VariationalELBO
@@ -172,7 +173,7 @@ def test_fused_adam_and_flat_bucket_train_the_dgp_like_torch_adam():
     B, S = 256, 3
     x, y = torch.randn(B, 3, generator=g).cuda(), torch.randn(B, generator=g).cuda()
     eps = [torch.randn(S, B, 2, generator=g)]
-    opt_a = FusedAdam(model_a.parameters(), lr=0.01)
+    opt_a = FusedAdam(model_a.parameters(), lr=0.01, grads_as_views=grads_as_views)
     opt_b = torch.optim.Adam(model_b.parameters(), lr=0.01)
     losses = []
     for model, opt in ((model_a, opt_a), (model_b, opt_b)):
