@@ -235,12 +235,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g, T alpha, const
         pb[p] = MODE_B == 0 ? Bb + (n0 + br[p]) * g.sbn + bk[p] : Bb + (n0 + br[p]) + (int64_t)bk[p] * g.sbk;
     const int64_t stepA = MODE_A == 0 ? 1 : g.sak, stepB = MODE_B == 0 ? 1 : g.sbk;
 
-    Frag4<T> ra[PA], rb[PB];
+    // float64 tiles are small (16 MFMAs per wave and K-tile, 0.25 us): one K-tile of prefetch does not cover a
+    // global-load latency, so they keep TWO K-tiles in flight in two register sets.
+    constexpr bool PF2 = sizeof(T) == 8 && KSC == 0;
+    Frag4<T> ra0[PA], rb0[PB], ra1[PF2 ? PA : 1], rb1[PF2 ? PB : 1];
     Frag4<T> rks[KSC ? PB : 1];
     const T* ksb = KSC ? reinterpret_cast<const T*>(ep.ks) + bb * g.K : nullptr;
     const bool ks_vec = KSC && ((uintptr_t)ksb % (4 * sizeof(T)) == 0);
 
-    auto gload = [&](int64_t k0) {
+    auto gload = [&](int64_t k0, Frag4<T>* ra, Frag4<T>* rb) {
         const bool kfull = k0 + BK <= kend;
         const bool a_diag = (aL || aU) && (k0 < m0 + BM) && (k0 + BK > m0);
         const bool b_diag = (bL || bU) && (k0 < n0 + BN) && (k0 + BK > n0);
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g, T alpha, const
             }
         }
     };
-    auto sstore = [&](int buf) {
+    auto sstore = [&](int buf, Frag4<T>* ra, Frag4<T>* rb) {
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
             if (MODE_A == 0) {
@@ -308,36 +311,61 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g, T alpha, const
         }
     };
 
-    if (nt > 0) {
-        gload(kbeg);
-        sstore(0);
-        __syncthreads();
-        const int kr = MF::krow(lane), mc = MF::mcol(lane);
-        for (int64_t t = 0; t < nt; ++t) {
-            const int buf = (int)(t & 1);
-            if (t + 1 < nt) gload(kbeg + (t + 1) * BK);             // next tile -> registers (in flight)
-            const T* as = &As[buf][kr * LDA + wm0 + mc];
-            const T* bs = &Bs[buf][kr * LDB + wn0 + mc];
-            // operand fragments of KCH k-steps first (LDS latency overlaps the MFMA stream), then the MFMAs
+    const int kr = MF::krow(lane), mc = MF::mcol(lane);
+    auto compute = [&](int buf) {
+        const T* as = &As[buf][kr * LDA + wm0 + mc];
+        const T* bs = &Bs[buf][kr * LDB + wn0 + mc];
+        // operand fragments of KCH k-steps first (LDS latency overlaps the MFMA stream), then the MFMAs
 #pragma unroll
-            for (int kc = 0; kc < NKK; kc += KCH) {
-                T af[KCH][TM], bf[KCH][TN];
+        for (int kc = 0; kc < NKK; kc += KCH) {
+            T af[KCH][TM], bf[KCH][TN];
 #pragma unroll
-                for (int kk = 0; kk < KCH; ++kk) {
+            for (int kk = 0; kk < KCH; ++kk) {
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) af[kk][i] = as[(kc + kk) * KS * LDA + i * MT];
+                for (int i = 0; i < TM; ++i) af[kk][i] = as[(kc + kk) * KS * LDA + i * MT];
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) bf[kk][j] = bs[(kc + kk) * KS * LDB + j * MT];
-                }
-#pragma unroll
-                for (int kk = 0; kk < KCH; ++kk)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(af[kk][i], bf[kk][j], acc[i][j]);
+                for (int j = 0; j < TN; ++j) bf[kk][j] = bs[(kc + kk) * KS * LDB + j * MT];
             }
-            if (t + 1 < nt) sstore(buf ^ 1);
+#pragma unroll
+            for (int kk = 0; kk < KCH; ++kk)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(af[kk][i], bf[kk][j], acc[i][j]);
+        }
+    };
+    if constexpr (PF2) {
+        if (nt > 0) {
+            gload(kbeg, ra0, rb0);
+            if (nt > 1) gload(kbeg + BK, ra1, rb1);
+            sstore(0, ra0, rb0);
             __syncthreads();
+            for (int64_t t = 0; t < nt; t += 2) {
+                // even step: set 0 is free (stored), set 1 holds tile t+1
+                if (t + 2 < nt) gload(kbeg + (t + 2) * BK, ra0, rb0);
+                compute(0);
+                if (t + 1 < nt) sstore(1, ra1, rb1);
+                __syncthreads();
+                if (t + 1 >= nt) break;
+                // odd step: set 1 is free, set 0 holds tile t+2
+                if (t + 3 < nt) gload(kbeg + (t + 3) * BK, ra1, rb1);
+                compute(1);
+                if (t + 2 < nt) sstore(0, ra0, rb0);
+                __syncthreads();
+            }
+        }
+    } else {
+        if (nt > 0) {
+            gload(kbeg, ra0, rb0);
+            sstore(0, ra0, rb0);
+            __syncthreads();
+            for (int64_t t = 0; t < nt; ++t) {
+                const int buf = (int)(t & 1);
+                if (t + 1 < nt) gload(kbeg + (t + 1) * BK, ra0, rb0);      // next tile -> registers (in flight)
+                compute(buf);
+                if (t + 1 < nt) sstore(buf ^ 1, ra0, rb0);
+                __syncthreads();
+            }
         }
     }
 
