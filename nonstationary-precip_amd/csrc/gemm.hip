@@ -126,7 +126,7 @@ __device__ __forceinline__ Frag4<T> load_operand4(const T* base, int64_t sr, int
 }
 
 // MODE_A / MODE_B: 0 = operand contiguous along k, 1 = contiguous along m (n).
-template <typename T, int BM, int BN, int BK, int MODE_A, int MODE_B, int EPI = 0, int KSC = 0>
+template <typename T, int BM, int BN, int BK, int MODE_A, int MODE_B, int EPI = 0, int KSC = 0, int PF = 0>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g, T alpha, const T* __restrict__ A,
                                                    const T* __restrict__ B, T beta, T* __restrict__ C,
                                                    T* __restrict__ slabs, Epi ep) {
@@ -235,9 +235,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g, T alpha, const
         pb[p] = MODE_B == 0 ? Bb + (n0 + br[p]) * g.sbn + bk[p] : Bb + (n0 + br[p]) + (int64_t)bk[p] * g.sbk;
     const int64_t stepA = MODE_A == 0 ? 1 : g.sak, stepB = MODE_B == 0 ? 1 : g.sbk;
 
-    // float64 tiles are small (16 MFMAs per wave and K-tile, 0.25 us): one K-tile of prefetch does not cover a
-    // global-load latency, so they keep TWO K-tiles in flight in two register sets.
-    constexpr bool PF2 = sizeof(T) == 8 && KSC == 0;
+    // PF = 1 (float64, grids of at most one round): the tile is small (16 MFMAs per wave and K-tile, 0.25 us),
+    // one K-tile of prefetch does not cover a global-load latency, so TWO K-tiles are kept in flight in two
+    // register sets.  It costs a wave of occupancy (3 -> 2 per SIMD), which multi-round grids need more
+    // (N=16384 potrf: 39 ms without, 51 ms with), so those keep PF = 0.
+    constexpr bool PF2 = PF != 0 && sizeof(T) == 8 && KSC == 0;
     Frag4<T> ra0[PA], rb0[PB], ra1[PF2 ? PA : 1], rb1[PF2 ? PB : 1];
     Frag4<T> rks[KSC ? PB : 1];
     const T* ksb = KSC ? reinterpret_cast<const T*>(ep.ks) + bb * g.K : nullptr;
@@ -605,6 +607,7 @@ int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam,
     if (epi) ep = *epi;
     if (tiles_m_out) *tiles_m_out = g.tiles_m;
     const int ekind = ep.kind, eks = ep.ks != nullptr;
+    const bool one_round = ngrid * nb * g.ksplit <= 256 * 3;      // f64: latency-bound single-round grids take PF = 1
     if (ekind != 0 && (g.ksplit != 1 || beta != T(0) || (flags & NSGP_GEMM_C_LOWER))) return -30;
 #define NSGP_LAUNCH_X(BMN, MA, MB, EP, KS)                                                                \
     do {                                                                                                  \
@@ -641,6 +644,11 @@ int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam,
         constexpr int pa = (MA == 0 && sizeof(T) == 4) ? 1 : Mfma<T>::PAD;                                \
         constexpr int pb = (MB == 0 && sizeof(T) == 4) ? 1 : Mfma<T>::PAD;                                \
         constexpr size_t lds = 2 * BKc * ((BMN + pa) + (BMN + pb)) * sizeof(T);                           \
+        if (sizeof(T) == 8 && one_round) {                                                                \
+            hipLaunchKernelGGL((gemm_kernel<T, BMN, BMN, BKc, MA, MB, 0, 0, (sizeof(T) == 8 ? 1 : 0)>), grid,   \
+                               dim3(256), lds, st, g, alpha, A, B, beta, C, slabs, ep);                   \
+            break;                                                                                        \
+        }                                                                                                 \
         auto kern = gemm_kernel<T, BMN, BMN, BKc, MA, MB>;                                                \
         static bool attr_done = false;                                                                    \
         if (!attr_done && lds > 65536) {                                                                  \
