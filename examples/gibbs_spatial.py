@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""Non-stationary (Gibbs-kernel) exact GP on data/uib_spatial.csv: MAP training of the per-point
+lengthscales, then prediction -- the flow of the reference's experiments/spatial_exp.py:108-250.
+
+Per split (seed BASE_SEED + i): z-score x and y, rng.shuffle the indices, first ceil(80 %) train;
+LogNormalPriorProcess(input_dim=2) with frozen hyper-parameters (outputscale 1, lengthscale 1.3,
+mean log 0.3; spatial_exp.py:160-169); DiagonalExactGP in float64 with noise 0.011 and outputscale
+0.644 fixed (spatial_exp.py:176-186); Adam(lr=0.01) on -ExactMarginalLogLikelihood (which adds the
+prior's log-density of the lengthscale field); likelihood(model.predict(x_test)) for the metrics
+rmse*stdy / nlpd (utils/metrics.py:36-45) and model.predict(x) for the full-field posterior.
+(The reference script evaluates `likelihood(model(x_test))` at spatial_exp.py:217, which sends a
+train-sized `ell1` through gpytorch's joint [train; test] covariance and is shape-inconsistent for this
+kernel; `predict()` (models/nonstationary_models.py:45-62) is the model's own predictive and is what is used here.)
+`--inference sparse --M 250` runs DiagonalSparseGP with k-means inducing points instead
+(scikit-learn's KMeans; the reference uses pymc3's helper, spatial_exp.py:153).
+
+    python examples/gibbs_spatial.py --splits 1 --iters 500
+"""
+import argparse
+import math
+
+import _path  # noqa: F401
+import numpy as np
+import torch
+
+from models.gibbs_kernels import LogNormalPriorProcess          # registers nsgp.gp as `gpytorch` if needed
+from models.nonstationary_models import DiagonalExactGP, DiagonalSparseGP
+import gpytorch                                                  # noqa: E402
+import utils.dataprep as dp                                      # noqa: E402
+from utils.config import BASE_SEED, DATASET_DIR                  # noqa: E402
+from utils.metrics import nlpd, rmse                             # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument('--csv', default=str(DATASET_DIR / 'uib_spatial.csv'))
+    ap.add_argument('--splits', type=int, default=10)
+    ap.add_argument('--iters', type=int, default=5000)
+    ap.add_argument('--inference', choices=('exact', 'sparse'), default='exact')
+    ap.add_argument('--M', type=int, default=250)
+    ap.add_argument('--prior_scale', type=float, default=1.0)
+    ap.add_argument('--prior_ell', type=float, default=1.3)
+    ap.add_argument('--prior_mean', type=float, default=0.3)
+    ap.add_argument('--noise', type=float, default=0.011)
+    ap.add_argument('--scale', type=float, default=0.644)
+    ap.add_argument('--lr', type=float, default=0.01)
+    args = ap.parse_args()
+    if not torch.cuda.is_available():
+        raise SystemExit('examples/gibbs_spatial.py needs the MI355X: nsgp has no CPU path')
+    device = 'cuda'
+    data = dp.download_data(args.csv).double()
+    x, y = data[:, :2], data[:, -1]
+    rmses, nlpds = [], []
+    for i in range(args.splits):
+        rng = np.random.default_rng(BASE_SEED + i)
+        torch.manual_seed(BASE_SEED + i)
+        stdx, meanx = torch.std_mean(x, dim=-2)
+        x_norm = (x - meanx) / stdx
+        stdy, meany = torch.std_mean(y)
+        y_norm = (y - meany) / stdy
+        num_train = math.ceil(0.8 * y.shape[0])
+        idx = np.arange(y.shape[0])
+        rng.shuffle(idx)
+        tr, te = idx[:num_train], idx[num_train:]
+        x_train, y_train = x_norm[tr].to(device), y_norm[tr].to(device)
+        x_test, y_test = x_norm[te].to(device), y_norm[te].to(device)
+
+        prior = LogNormalPriorProcess(input_dim=2).to(device).double()
+        prior.covar_module.outputscale = args.prior_scale * torch.ones_like(prior.covar_module.outputscale)
+        prior.covar_module.base_kernel.lengthscale = args.prior_ell * torch.ones_like(
+            prior.covar_module.base_kernel.lengthscale)
+        prior.mean_module.constant = torch.nn.Parameter(
+            math.log(args.prior_mean) * torch.ones_like(prior.mean_module.constant))
+        for p in prior.parameters():
+            p.requires_grad = False
+
+        likelihood = gpytorch.likelihoods.GaussianLikelihood().double()
+        if args.inference == 'exact':
+            model = DiagonalExactGP(x_train, y_train, likelihood, prior, num_dim=2).to(device).double()
+        else:
+            from sklearn.cluster import KMeans
+            z = torch.tensor(KMeans(args.M, n_init=1, random_state=BASE_SEED + i).fit(x_train.cpu().numpy())
+                             .cluster_centers_).double()
+            model = DiagonalSparseGP(x_train, y_train, likelihood, prior, z, num_dim=2).to(device).double()
+        if args.noise > 0:
+            model.likelihood.noise = args.noise
+            for p in model.likelihood.noise_covar.parameters():
+                p.requires_grad = False
+        if args.scale > 0:
+            model.covar_module.outputscale = args.scale
+            model.covar_module._parameters['raw_outputscale'].requires_grad = False
+
+        model.train()
+        likelihood.train()
+        optimizer = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=args.lr)
+        mll = gpytorch.mlls.ExactMarginalLogLikelihood(likelihood, model)
+        for it in range(args.iters):
+            optimizer.zero_grad()
+            with gpytorch.settings.max_cg_iterations(4000):
+                loss = -mll(model(x_train), y_train)
+            loss.backward()
+            if it % max(1, args.iters // 10) == 0:
+                print(f'  split {i} iter {it + 1}/{args.iters} loss {float(loss):.4f} '
+                      f'amplitude {float(model.covar_module.outputscale):.3f} noise {float(model.likelihood.noise):.3f}',
+                      flush=True)
+            optimizer.step()
+
+        model.eval()
+        likelihood.eval()
+        with torch.no_grad():
+            pred = likelihood(model.predict(x_test))
+            rm = float(rmse(pred.loc, y_test, stdy.to(device)))
+            nl = float(nlpd(pred, y_test, stdy.to(device)))
+            full = model.predict(x_norm.to(device))
+        print(f'split {i}: RMSE test = {rm:.4f}  NLPD test = {nl:.4f}  '
+              f'full-field posterior mean range [{float(full.loc.min()):.3f}, {float(full.loc.max()):.3f}]', flush=True)
+        rmses.append(rm)
+        nlpds.append(nl)
+    k = math.sqrt(max(len(rmses), 1))
+    print(f'Final RMSE across splits: {np.mean(rmses):.4f} +- {np.std(rmses) / k:.4f}')
+    print(f'Final NLPD across splits: {np.mean(nlpds):.4f} +- {np.std(nlpds) / k:.4f}')
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,56 @@
+"""The callers either side of the hot path: examples/deepgp_spatial.py and
+examples/gibbs_spatial.py drive the drop-in `models.*` / `utils.*` / `gpytorch` surface exactly like the
+reference's experiments/deepgp_spatial_bench.py and experiments/spatial_exp.py.  Short runs on the bundled
+uib_spatial.csv; the bands are sanity bands (the reference's results/*.csv come from unseeded 400-epoch runs:
+trained 2-layer DGP RMSE 0.5-0.6 in raw units), not parity assertions."""
+import importlib.util
+import os
+import sys
+import types
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load(name):
+    ex = os.path.join(ROOT, 'examples')
+    if ex not in sys.path:
+        sys.path.insert(0, ex)
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ex, name + '.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_deepgp_spatial_example_trains_and_predicts(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    mod = _load('deepgp_spatial')
+    import utils.dataprep as dp
+    from utils.config import DATASET_DIR
+    args = types.SimpleNamespace(layers=1, inducing=64, batch=315, lr=0.01, epochs=120, samples=3,
+                                 verbose=False, out=str(tmp_path / 'pred.csv'))
+    dataset = dp.download_data(str(DATASET_DIR / 'uib_spatial.csv'))
+    rm, nl, loss, frame = mod.run_split(dataset, 0, args, torch.device('cuda', 0))
+    assert list(frame.columns) == ['pred', 'std', 'lat', 'lon'] and len(frame) == 79
+    # whitened-target ELBO loss starts near 1.6; a trained model is well below 1.2 and predicts better than the
+    # target's standard deviation (raw std of tp on this CSV is ~1.1): sanity band only
+    assert loss < 1.2
+    assert 0.2 < rm < 0.9
+    assert abs(nl) < 5.0
+
+
+def test_gibbs_spatial_example_runs_exact_and_sparse(capsys, monkeypatch):
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    mod = _load('gibbs_spatial')
+    for extra in ([], ['--inference', 'sparse', '--M', '64']):
+        monkeypatch.setattr(sys, 'argv', ['gibbs_spatial.py', '--splits', '1', '--iters', '60'] + extra)
+        mod.main()
+        out = capsys.readouterr().out
+        line = [l for l in out.splitlines() if l.startswith('split 0:')][0]
+        rm = float(line.split('RMSE test =')[1].split()[0])
+        assert 0.1 < rm < 1.0, line
