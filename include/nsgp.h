@@ -139,6 +139,36 @@ int nsgp_gemm_f64(int64_t M, int64_t N, int64_t K, double alpha,
                   int64_t nb1, int64_t nb2, int flags, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * K2' Batched  os * RBF-ARD(x; ls_rbf) * Periodic(x; ls_per, period)  in one launch:
+ *       k = os_b exp(-1/2 sum_d ((x_d - x'_d)/ls_rbf[b,d])^2) exp(-2 sin^2(pi |x - x'| / period_b) / ls_per_b)
+ *     replaces ScaleKernel(RBFKernel(active_dims=0) * PeriodicKernel(active_dims=0), GreaterThan(7))
+ *     (models/spatio_temporal_models.py:22,42; experiments/temporal_exp.py:39) -- gpytorch < 1.9
+ *     PeriodicKernel semantics as recalled in SURVEY A.2/A.7 (distance of x/period, division by ls_per).
+ *     ls_rbf == NULL drops the RBF factor (plain PeriodicKernel); os == NULL means 1.  x as in K2.
+ *     backward: g_x1/g_x2 (batch,n,D) per batch (NULL to skip), g_ls_rbf (batch,D), g_ls_per, g_period,
+ *     g_os (batch); workspace from nsgp_rbf_periodic_build_bwd_workspace.
+ * ------------------------------------------------------------------------------------------ */
+int nsgp_rbf_periodic_build_fwd_f32(const float* x1, const float* x2, const float* ls_rbf, const float* ls_per,
+                                    const float* period, const float* os, int64_t batch, int64_t n1, int64_t n2, int D,
+                                    int64_t sx1, int64_t sx2, float diag_add, float* K, int64_t ldk, int64_t sK,
+                                    void* stream);
+int nsgp_rbf_periodic_build_fwd_f64(const double* x1, const double* x2, const double* ls_rbf, const double* ls_per,
+                                    const double* period, const double* os, int64_t batch, int64_t n1, int64_t n2,
+                                    int D, int64_t sx1, int64_t sx2, double diag_add, double* K, int64_t ldk,
+                                    int64_t sK, void* stream);
+size_t nsgp_rbf_periodic_build_bwd_workspace(int64_t batch, int64_t n1, int64_t n2, int D, int elem_size);
+int nsgp_rbf_periodic_build_bwd_f32(const float* x1, const float* x2, const float* ls_rbf, const float* ls_per,
+                                    const float* period, const float* os, int64_t batch, int64_t n1, int64_t n2, int D,
+                                    int64_t sx1, int64_t sx2, const float* G, int64_t ldg, int64_t sG, float* g_x1,
+                                    float* g_x2, float* g_ls_rbf, float* g_ls_per, float* g_period, float* g_os,
+                                    void* ws, size_t ws_bytes, void* stream);
+int nsgp_rbf_periodic_build_bwd_f64(const double* x1, const double* x2, const double* ls_rbf, const double* ls_per,
+                                    const double* period, const double* os, int64_t batch, int64_t n1, int64_t n2,
+                                    int D, int64_t sx1, int64_t sx2, const double* G, int64_t ldg, int64_t sG,
+                                    double* g_x1, double* g_x2, double* g_ls_rbf, double* g_ls_per, double* g_period,
+                                    double* g_os, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * K4  Blocked right-looking Cholesky A = L L^T (lower, in place, strict upper zeroed), batched.
  *     Panel: LDS-resident 64x64 diagonal factor + explicit inverse; trailing update on MFMA.
  *     replaces psd_safe_cholesky (models/gibbs_kernels.py:201,298), gpytorch

@@ -141,6 +141,79 @@ template <typename T, int D> struct RbfOp {
     }
 };
 
+// K2' batched  os * RBF-ARD(x; ls_r) * Periodic(x; ls_p, period):
+//   k = os * exp(-1/2 sum_d ((x_d - x'_d)/ls_r,d)^2) * exp(-2 sin^2(pi |x - x'| / period) / ls_p)
+// (gpytorch PeriodicKernel < 1.9 as recalled in SURVEY A.2/A.7: Euclidean distance of x / period, division by
+// the lengthscale, not its square).  One launch builds ScaleKernel(RBFKernel * PeriodicKernel) of
+// models/spatio_temporal_models.py:22,42 and experiments/temporal_exp.py:39; ls_r == nullptr drops the RBF
+// factor (plain PeriodicKernel), os == nullptr means 1.
+template <typename T, int D> struct RbfPeriodicOp {
+    static constexpr int DM = DimMax<D>::v;
+    static constexpr int NR = DM, NC = DM, NG = DM + 3;        // globals: ls_r[D], ls_p, period, os
+    const T *x1, *x2, *lsr, *lsp, *per, *os;
+    int64_t n1, n2, sx1, sx2;
+    int Drt;
+    struct P { T x[DM]; };
+    __device__ __forceinline__ P row(int64_t b, int64_t i) const {
+        P p;
+#pragma unroll
+        for (int d = 0; d < DM; ++d) p.x[d] = (D || d < Drt) ? x1[b * sx1 + i * Drt + d] : T(0);
+        return p;
+    }
+    __device__ __forceinline__ P col(int64_t b, int64_t j) const {
+        P p;
+#pragma unroll
+        for (int d = 0; d < DM; ++d) p.x[d] = (D || d < Drt) ? x2[b * sx2 + j * Drt + d] : T(0);
+        return p;
+    }
+    // exponent pieces: q = sum_d (delta_d / ls_r,d)^2, r = |delta|, (s, c) = sincos(pi r / period)
+    __device__ __forceinline__ T base(int64_t b, const P& r, const P& c, T& rr, T& sn, T& cs) const {
+        T q = T(0), r2 = T(0);
+#pragma unroll
+        for (int d = 0; d < DM; ++d) {
+            if (D || d < Drt) {
+                const T df = r.x[d] - c.x[d];
+                r2 += df * df;
+                if (lsr) { const T il = T(1) / lsr[b * Drt + d]; q += df * df * il * il; }
+            }
+        }
+        rr = t_sqrt(r2);
+        const T u = T(3.14159265358979323846) * rr / per[b];
+        sn = sin(u); cs = cos(u);
+        return t_exp(T(-0.5) * q - T(2) * sn * sn / lsp[b]);
+    }
+    __device__ __forceinline__ T eval(int64_t b, const P& r, const P& c) const {
+        T rr, sn, cs;
+        const T k = base(b, r, c, rr, sn, cs);
+        return os ? os[b] * k : k;
+    }
+    __device__ __forceinline__ void grad(int64_t b, const P& r, const P& c, T g, T* ra, T* ca, T* ga) const {
+        T rr, sn, cs;
+        const T kb = base(b, r, c, rr, sn, cs);
+        ga[DM + 2] += g * kb;                                              // d/d os
+        const T w = g * kb * (os ? os[b] : T(1));
+        const T ilp = T(1) / lsp[b], ip = T(1) / per[b];
+        ga[DM] += w * T(2) * sn * sn * ilp * ilp;                          // d/d ls_p
+        const T dsdu = T(4) * ilp * sn * cs * T(3.14159265358979323846);   // -(d exponent / d u), u = pi r / period
+        ga[DM + 1] += w * dsdu * rr * ip * ip;                             // d/d period  (du/dp = -pi r / p^2)
+        const T dr = rr > T(0) ? dsdu * ip / rr : T(0);                    // -(d exponent / d r) / r
+#pragma unroll
+        for (int d = 0; d < DM; ++d) {
+            if (D || d < Drt) {
+                const T df = r.x[d] - c.x[d];
+                T gx = -dr * df;                                           // d exponent / d x1_d (periodic part)
+                if (lsr) {
+                    const T il = T(1) / lsr[b * Drt + d];
+                    gx -= df * il * il;
+                    ga[d] += w * df * df * il * il * il;                   // d/d ls_r,d
+                }
+                ra[d] += w * gx;
+                ca[d] -= w * gx;
+            }
+        }
+    }
+};
+
 template <typename T> struct PsOp {
     static constexpr int NR = 4, NC = 4, NG = 1;      // NG unused (kept 1 for array sizing)
     const T *x1, *x2, *s1, *s2;
@@ -556,6 +629,58 @@ int ps_bwd(const T* x1, const T* x2, const T* s1, const T* s2, int64_t n1, int64
     return launch_bwd<T>(op, 1, n1, n2, G, ldg, 0, rows, cols, globs, ws, wsb, stream);
 }
 
+template <typename T, int D>
+int rbfper_fwd_d(const T* x1, const T* x2, const T* lsr, const T* lsp, const T* per, const T* os, int64_t batch,
+                 int64_t n1, int64_t n2, int Drt, int64_t sx1, int64_t sx2, T diag_add, T* K, int64_t ldk, int64_t sK,
+                 void* stream) {
+    RbfPeriodicOp<T, D> op{x1, x2, lsr, lsp, per, os, n1, n2, sx1, sx2, Drt};
+    return launch_fwd<T>(op, batch, n1, n2, diag_add, (const T*)nullptr, K, ldk, sK, stream);
+}
+template <typename T>
+int rbfper_fwd(const T* x1, const T* x2, const T* lsr, const T* lsp, const T* per, const T* os, int64_t batch,
+               int64_t n1, int64_t n2, int D, int64_t sx1, int64_t sx2, T diag_add, T* K, int64_t ldk, int64_t sK,
+               void* stream) {
+    if (!x1) return -1; if (!x2) return -2; if (!lsp) return -4; if (!per) return -5;
+    if (batch < 0) return -7; if (n1 < 0) return -8; if (n2 < 0) return -9; if (D < 1 || D > NSGP_MAX_DIM) return -10;
+    if (!K && batch * n1 * n2 > 0) return -14; if (ldk < n2) return -15;
+    switch (D) {
+        case 1: return rbfper_fwd_d<T, 1>(x1, x2, lsr, lsp, per, os, batch, n1, n2, D, sx1, sx2, diag_add, K, ldk, sK, stream);
+        case 2: return rbfper_fwd_d<T, 2>(x1, x2, lsr, lsp, per, os, batch, n1, n2, D, sx1, sx2, diag_add, K, ldk, sK, stream);
+        default: return rbfper_fwd_d<T, 0>(x1, x2, lsr, lsp, per, os, batch, n1, n2, D, sx1, sx2, diag_add, K, ldk, sK, stream);
+    }
+}
+template <typename T, int D>
+int rbfper_bwd_d(const T* x1, const T* x2, const T* lsr, const T* lsp, const T* per, const T* os, int64_t batch,
+                 int64_t n1, int64_t n2, int Drt, int64_t sx1, int64_t sx2, const T* G, int64_t ldg, int64_t sG,
+                 T* g_x1, T* g_x2, T* g_lsr, T* g_lsp, T* g_per, T* g_os, void* ws, size_t wsb, void* stream) {
+    using Op = RbfPeriodicOp<T, D>;
+    Op op{x1, x2, lsr, lsp, per, os, n1, n2, sx1, sx2, Drt};
+    constexpr int DM = Op::DM;
+    OutDesc<T> rows = empty_desc<T>(Op::NR), cols = empty_desc<T>(Op::NC), globs = empty_desc<T>(Op::NG);
+    for (int d = 0; d < Drt; ++d) {
+        if (g_x1) { rows.ptr[d] = g_x1 + d; rows.stride[d] = Drt; rows.bstride[d] = n1 * Drt; }
+        if (g_x2) { cols.ptr[d] = g_x2 + d; cols.stride[d] = Drt; cols.bstride[d] = n2 * Drt; }
+        if (g_lsr && lsr) { globs.ptr[d] = g_lsr + d; globs.bstride[d] = Drt; }
+    }
+    if (g_lsp) { globs.ptr[DM] = g_lsp; globs.bstride[DM] = 1; }
+    if (g_per) { globs.ptr[DM + 1] = g_per; globs.bstride[DM + 1] = 1; }
+    if (g_os) { globs.ptr[DM + 2] = g_os; globs.bstride[DM + 2] = 1; }
+    return launch_bwd<T>(op, batch, n1, n2, G, ldg, sG, rows, cols, globs, ws, wsb, stream);
+}
+template <typename T>
+int rbfper_bwd(const T* x1, const T* x2, const T* lsr, const T* lsp, const T* per, const T* os, int64_t batch,
+               int64_t n1, int64_t n2, int D, int64_t sx1, int64_t sx2, const T* G, int64_t ldg, int64_t sG, T* g_x1,
+               T* g_x2, T* g_lsr, T* g_lsp, T* g_per, T* g_os, void* ws, size_t wsb, void* stream) {
+    if (!x1) return -1; if (!x2) return -2; if (!lsp) return -4; if (!per) return -5;
+    if (batch < 0) return -7; if (n1 < 0) return -8; if (n2 < 0) return -9; if (D < 1 || D > NSGP_MAX_DIM) return -10;
+    if (!G && batch * n1 * n2 > 0) return -13; if (ldg < n2) return -14;
+    switch (D) {
+        case 1: return rbfper_bwd_d<T, 1>(x1, x2, lsr, lsp, per, os, batch, n1, n2, D, sx1, sx2, G, ldg, sG, g_x1, g_x2, g_lsr, g_lsp, g_per, g_os, ws, wsb, stream);
+        case 2: return rbfper_bwd_d<T, 2>(x1, x2, lsr, lsp, per, os, batch, n1, n2, D, sx1, sx2, G, ldg, sG, g_x1, g_x2, g_lsr, g_lsp, g_per, g_os, ws, wsb, stream);
+        default: return rbfper_bwd_d<T, 0>(x1, x2, lsr, lsp, per, os, batch, n1, n2, D, sx1, sx2, G, ldg, sG, g_x1, g_x2, g_lsr, g_lsp, g_per, g_os, ws, wsb, stream);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -633,6 +758,40 @@ int nsgp_ps2d_build_bwd_f64(const double* x1, const double* x2, const double* s1
                             int64_t n2, double jit, const double* G, int64_t ldg, double* g_s1, double* g_s2,
                             void* ws, size_t wsb, void* stream) {
     return ps_bwd<double>(x1, x2, s1, s2, n1, n2, jit, G, ldg, g_s1, g_s2, ws, wsb, stream);
+}
+
+
+int nsgp_rbf_periodic_build_fwd_f32(const float* x1, const float* x2, const float* ls_rbf, const float* ls_per,
+                                    const float* period, const float* os, int64_t batch, int64_t n1, int64_t n2, int D,
+                                    int64_t sx1, int64_t sx2, float diag_add, float* K, int64_t ldk, int64_t sK,
+                                    void* stream) {
+    return rbfper_fwd<float>(x1, x2, ls_rbf, ls_per, period, os, batch, n1, n2, D, sx1, sx2, diag_add, K, ldk, sK, stream);
+}
+int nsgp_rbf_periodic_build_fwd_f64(const double* x1, const double* x2, const double* ls_rbf, const double* ls_per,
+                                    const double* period, const double* os, int64_t batch, int64_t n1, int64_t n2,
+                                    int D, int64_t sx1, int64_t sx2, double diag_add, double* K, int64_t ldk,
+                                    int64_t sK, void* stream) {
+    return rbfper_fwd<double>(x1, x2, ls_rbf, ls_per, period, os, batch, n1, n2, D, sx1, sx2, diag_add, K, ldk, sK, stream);
+}
+size_t nsgp_rbf_periodic_build_bwd_workspace(int64_t batch, int64_t n1, int64_t n2, int D, int elem_size) {
+    (void)D;
+    return bwd_ws_elems<RbfPeriodicOp<double, 0>>(batch, n1, n2) * (size_t)elem_size + 256;
+}
+int nsgp_rbf_periodic_build_bwd_f32(const float* x1, const float* x2, const float* ls_rbf, const float* ls_per,
+                                    const float* period, const float* os, int64_t batch, int64_t n1, int64_t n2, int D,
+                                    int64_t sx1, int64_t sx2, const float* G, int64_t ldg, int64_t sG, float* g_x1,
+                                    float* g_x2, float* g_ls_rbf, float* g_ls_per, float* g_period, float* g_os,
+                                    void* ws, size_t wsb, void* stream) {
+    return rbfper_bwd<float>(x1, x2, ls_rbf, ls_per, period, os, batch, n1, n2, D, sx1, sx2, G, ldg, sG, g_x1, g_x2,
+                             g_ls_rbf, g_ls_per, g_period, g_os, ws, wsb, stream);
+}
+int nsgp_rbf_periodic_build_bwd_f64(const double* x1, const double* x2, const double* ls_rbf, const double* ls_per,
+                                    const double* period, const double* os, int64_t batch, int64_t n1, int64_t n2,
+                                    int D, int64_t sx1, int64_t sx2, const double* G, int64_t ldg, int64_t sG,
+                                    double* g_x1, double* g_x2, double* g_ls_rbf, double* g_ls_per, double* g_period,
+                                    double* g_os, void* ws, size_t wsb, void* stream) {
+    return rbfper_bwd<double>(x1, x2, ls_rbf, ls_per, period, os, batch, n1, n2, D, sx1, sx2, G, ldg, sG, g_x1, g_x2,
+                              g_ls_rbf, g_ls_per, g_period, g_os, ws, wsb, stream);
 }
 
 }  // extern "C"

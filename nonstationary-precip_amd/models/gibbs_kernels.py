@@ -21,6 +21,7 @@ import torch
 
 import nsgp.gp as gpytorch
 from nsgp import ops
+from nsgp.gp.utils.cholesky import chol_inv_safe
 from nsgp.gp import settings
 from nsgp.gp.kernels import same_points
 from nsgp.gp.lazy import (delazify, LowRankRootLazyTensor, LowRankRootAddedDiagLazyTensor, DiagLazyTensor,
@@ -153,7 +154,7 @@ class InducingGibbsKernel(gpytorch.kernels.InducingPointKernel):
         """R with R R^T = Kzz^-1: the reference's triangular_solve(I, chol_upper(Kzz)) = U^-1 = (L^-1)^T."""
         if not self.training and hasattr(self, '_cached_kernel_inv_root'):
             return self._cached_kernel_inv_root
-        W, info = ops.chol_inv(self._inducing_mat(ell))          # W = L^-1 (lower), no jitter
+        W = chol_inv_safe(self._inducing_mat(ell))               # W = L^-1 (lower); jitter only on failure
         res = W.transpose(-1, -2)
         if not self.training:
             self._cached_kernel_inv_root = res

@@ -209,28 +209,64 @@ class AdditiveKernel(Kernel):
         return res
 
 
+def _same_dims(a, b):
+    if a is None or b is None:
+        return a is None and b is None
+    return a.shape == b.shape and bool(torch.equal(a.cpu(), b.cpu()))
+
+
 class ProductKernel(Kernel):
     def __init__(self, *kernels):
         super().__init__()
         self.kernels = torch.nn.ModuleList(kernels)
 
-    def forward(self, x1, x2, diag=False, **params):
+    def _rbf_periodic(self):
+        """(rbf, periodic) when this is RBFKernel * PeriodicKernel on the same active dims: one fused launch."""
+        if len(self.kernels) != 2:
+            return None
+        a, b = self.kernels
+        if isinstance(a, PeriodicKernel) and isinstance(b, RBFKernel):
+            a, b = b, a
+        if isinstance(a, RBFKernel) and isinstance(b, PeriodicKernel) and _same_dims(a.active_dims, b.active_dims):
+            return a, b
+        return None
+
+    @property
+    def fuses_outputscale(self):
+        return self._rbf_periodic() is not None
+
+    def forward(self, x1, x2, diag=False, _outputscale=None, **params):
+        pair = self._rbf_periodic()
+        if pair is not None and not diag:
+            rbf, per = pair
+            if rbf.active_dims is not None:
+                x1, x2 = x1.index_select(-1, rbf.active_dims), x2.index_select(-1, rbf.active_dims)
+            return per.forward(x1, x2, _outputscale=_outputscale, _rbf=rbf)
         res = None
         for k in self.kernels:
             nxt = delazify(k(x1, x2, diag=diag, **params))
             res = nxt if res is None else res * nxt
+        if _outputscale is not None:
+            os_ = _outputscale
+            res = res * (os_.unsqueeze(-1) if (diag and os_.dim()) else
+                         (os_.view(*os_.shape, 1, 1) if os_.dim() else os_))
         return res
 
 
 class PeriodicKernel(Kernel):
-    """Declared for import compatibility (experiments/temporal_exp.py:15); its build kernel is a
-    SURVEY 8(f) "next" item and is not on the MI355X path yet."""
+    """exp(-2 sin^2(pi |x1 - x2| / period_length) / lengthscale)  [gpytorch < 1.9 as recalled, SURVEY A.2/A.7:
+    Euclidean distance of x / period, division by the lengthscale (not its square)]; used as
+    RBFKernel * PeriodicKernel on the time column (models/spatio_temporal_models.py:22,42,
+    experiments/temporal_exp.py:39).  Built by the fused RBF x Periodic gfx950 kernel (nsgp.ops.rbf_periodic_kernel)."""
     has_lengthscale = True
+    is_stationary = True
 
     def __init__(self, period_length_prior=None, period_length_constraint=None, **kwargs):
         super().__init__(**kwargs)
         self.register_parameter('raw_period_length', torch.nn.Parameter(torch.zeros(*self._batch_shape, 1, 1)))
         self.register_constraint('raw_period_length', period_length_constraint or Positive())
+        if period_length_prior is not None:
+            self.register_prior('period_length_prior', period_length_prior, lambda m: m.period_length)
 
     @property
     def period_length(self):
@@ -240,8 +276,39 @@ class PeriodicKernel(Kernel):
     def period_length(self, value):
         self._set_constrained('raw_period_length', value)
 
-    def forward(self, x1, x2, diag=False, **params):
-        raise NotImplementedError('PeriodicKernel has no MI355X build kernel yet (SURVEY 8f.1)')
+    def forward(self, x1, x2, diag=False, last_dim_is_batch=False, _outputscale=None, _rbf=None, **params):
+        ls, per = self.lengthscale, self.period_length                         # (*batch, 1, 1)
+        shapes = [ls.shape[:-2], per.shape[:-2], x1.shape[:-2], x2.shape[:-2]]
+        if _rbf is not None:
+            shapes.append(_rbf.lengthscale.shape[:-2])
+        bshape = torch.broadcast_shapes(*shapes)
+        B = bshape.numel() if len(bshape) else 1
+        D = x1.shape[-1]
+        flat = lambda t: t.expand(*bshape, 1, 1).reshape(B).contiguous()
+        ls_b, per_b = flat(ls), flat(per)
+        ls_rbf = None
+        if _rbf is not None:
+            lr = _rbf.lengthscale
+            ls_rbf = lr.expand(*bshape, 1, lr.shape[-1]).reshape(B, lr.shape[-1])
+            if ls_rbf.shape[-1] != D:
+                ls_rbf = ls_rbf.expand(B, D)
+            ls_rbf = ls_rbf.contiguous()
+        os_ = None
+        if _outputscale is not None:
+            os_ = (_outputscale.expand(bshape).reshape(B) if _outputscale.dim() else _outputscale.expand(B)).contiguous()
+        if diag:
+            d = x1 - x2
+            r = d.pow(2).sum(-1).sqrt()
+            res = torch.exp(-2.0 * torch.sin(math.pi * r / per.squeeze(-1)).pow(2) / ls.squeeze(-1))
+            if _rbf is not None:
+                res = res * torch.exp(-0.5 * (d / _rbf.lengthscale).pow(2).sum(-1))
+            if _outputscale is not None:
+                res = res * (_outputscale.unsqueeze(-1) if _outputscale.dim() else _outputscale)
+            return res
+        xa = x1.reshape(-1, *x1.shape[-2:]) if x1.dim() > 3 else x1
+        xb = x2.reshape(-1, *x2.shape[-2:]) if x2.dim() > 3 else x2
+        K = ops.rbf_periodic_kernel(_batched_inputs(xa, B), _batched_inputs(xb, B), ls_rbf, ls_b, per_b, os_)
+        return K.reshape(*bshape, K.shape[-2], K.shape[-1])
 
 
 class MaternKernel(Kernel):
@@ -257,8 +324,9 @@ class MaternKernel(Kernel):
 
 
 class InducingPointKernel(Kernel):
-    """gpytorch.kernels.InducingPointKernel: `inducing_points` is a learnable Parameter; the SGPR
-    arithmetic lives in the subclasses (models/gibbs_kernels.py:171-363)."""
+    """gpytorch.kernels.InducingPointKernel: `inducing_points` is a learnable Parameter; generic SGPR low-rank
+    covariance for stationary base kernels here, the Gibbs-kernel variants (lengthscales conditioned on the
+    inducing points) in the subclasses (models/gibbs_kernels.py:171-363)."""
 
     def __init__(self, base_kernel, inducing_points, likelihood, active_dims=None):
         super().__init__(active_dims=active_dims)
@@ -277,3 +345,53 @@ class InducingPointKernel(Kernel):
     def train(self, mode=True):
         self._clear_cache()
         return super().train(mode)
+
+    # ---- generic SGPR arithmetic (stationary base kernels; gpytorch InducingPointKernel) -------
+    def _inducing_mat(self):
+        if not self.training and hasattr(self, '_cached_kernel_mat'):
+            return self._cached_kernel_mat
+        res = delazify(self.base_kernel(self.inducing_points, self.inducing_points))
+        if not self.training:
+            self._cached_kernel_mat = res
+        return res
+
+    def _inducing_inv_root(self):
+        """R with R R^T = Kzz^-1 (= triangular_solve(I, chol_upper(Kzz)) = (L^-1)^T)."""
+        if not self.training and hasattr(self, '_cached_kernel_inv_root'):
+            return self._cached_kernel_inv_root
+        from .utils.cholesky import chol_inv_safe
+        res = chol_inv_safe(self._inducing_mat()).transpose(-1, -2)
+        if not self.training:
+            self._cached_kernel_inv_root = res
+        return res
+
+    def _get_covariance(self, x1, x2):
+        k_ux1 = delazify(self.base_kernel(x1, self.inducing_points))
+        R = self._inducing_inv_root()
+        root1 = ops.matmul(k_ux1, R, b_lower=False)
+        if same_points(x1, x2):
+            covar = LowRankRootLazyTensor(root1)
+            if not self.training and settings.sgpr_diagonal_correction.on():
+                correction = (self.base_kernel(x1, x2, diag=True) - covar.diag()).clamp(0, math.inf)
+                covar = LowRankRootAddedDiagLazyTensor(covar, DiagLazyTensor(correction))
+            return covar
+        k_ux2 = delazify(self.base_kernel(x2, self.inducing_points))
+        return MatmulLazyTensor(root1, ops.matmul(k_ux2, R, b_lower=False).transpose(-1, -2))
+
+    def _covar_diag(self, inputs):
+        if inputs.ndimension() == 1:
+            inputs = inputs.unsqueeze(1)
+        return DiagLazyTensor(self.base_kernel(inputs, diag=True))
+
+    def forward(self, x1, x2, diag=False, **kwargs):
+        covar = self._get_covariance(x1, x2)
+        if self.training:
+            if not same_points(x1, x2):
+                raise RuntimeError('x1 should equal x2 in training mode')
+            from .distributions import MultivariateNormal
+            from .mlls import InducingPointKernelAddedLossTerm
+            zero_mean = torch.zeros_like(x1.select(-1, 0))
+            term = InducingPointKernelAddedLossTerm(MultivariateNormal(zero_mean, self._covar_diag(x1)),
+                                                    MultivariateNormal(zero_mean, covar), self.likelihood)
+            self.update_added_loss_term('inducing_point_loss_term', term)
+        return covar.diag() if diag else covar

@@ -177,6 +177,66 @@ def rbf_build_bwd(x1, x2, ls, os_, G, need_x1=True, need_x2=True):
 
 
 # --------------------------------------------------------------------------------------------
+# K2' RBF-ARD x Periodic (one launch)
+# --------------------------------------------------------------------------------------------
+def _rbfper_args(x1, x2, ls_rbf, ls_per, period, os_):
+    ref = _chk(x1, x2, ls_rbf, ls_per, period, os_)
+    ls_per, period = _c(ls_per.reshape(-1)), _c(period.reshape(-1))
+    batch = ls_per.shape[0]
+    if period.shape[0] != batch:
+        raise BackendError('rbf_periodic_build: ls_per and period must be (batch,)')
+    D = x1.shape[-1]
+    if ls_rbf is not None:
+        ls_rbf = _c(ls_rbf.reshape(batch, -1))
+        if ls_rbf.shape[1] != D:
+            raise BackendError('rbf_periodic_build: ls_rbf must be (batch, D)')
+    if os_ is not None:
+        os_ = _c(os_.reshape(-1))
+        if os_.shape[0] != batch:
+            raise BackendError('rbf_periodic_build: os must be (batch,)')
+
+    def prep(x):
+        if x.dim() == 2 and x.shape[1] == D:
+            return _c(x), x.shape[0], 0
+        if x.dim() == 3 and x.shape[0] == batch and x.shape[2] == D:
+            x = _c(x)
+            return x, x.shape[1], x.shape[1] * D
+        raise BackendError(f'rbf_periodic_build: x shape {tuple(x.shape)} vs batch {batch}, D {D}')
+    x1, n1, sx1 = prep(x1)
+    x2, n2, sx2 = prep(x2)
+    return ref, x1, x2, ls_rbf, ls_per, period, os_, batch, n1, n2, D, sx1, sx2
+
+
+def rbf_periodic_build(x1, x2, ls_rbf, ls_per, period, os_, diag_add=0.0):
+    """K[b] = os[b] RBF-ARD(x; ls_rbf[b]) Periodic(x; ls_per[b], period[b]); ls_rbf / os_ may be None."""
+    ref, x1, x2, ls_rbf, ls_per, period, os_, batch, n1, n2, D, sx1, sx2 = _rbfper_args(x1, x2, ls_rbf, ls_per,
+                                                                                       period, os_)
+    K = torch.empty((batch, n1, n2), dtype=ref.dtype, device=ref.device)
+    _lib.call(f'nsgp_rbf_periodic_build_fwd_{_sfx(ref)}', _p(x1), _p(x2), _p(ls_rbf), _p(ls_per), _p(period), _p(os_),
+              batch, n1, n2, D, sx1, sx2, float(diag_add), _p(K), n2, n1 * n2, _stream())
+    return K
+
+
+def rbf_periodic_build_bwd(x1, x2, ls_rbf, ls_per, period, os_, G, need_x1=True, need_x2=True):
+    ref, x1, x2, ls_rbf, ls_per, period, os_, batch, n1, n2, D, sx1, sx2 = _rbfper_args(x1, x2, ls_rbf, ls_per,
+                                                                                       period, os_)
+    _chk(ref, G)
+    G = _c(G).reshape(batch, n1, n2)
+    new = lambda *shp: torch.empty(shp, dtype=ref.dtype, device=ref.device)
+    g_x1 = new(batch, n1, D) if need_x1 else None
+    g_x2 = new(batch, n2, D) if need_x2 else None
+    g_lr = new(batch, D) if ls_rbf is not None else None
+    g_lp, g_pe = new(batch), new(batch)
+    g_os = new(batch)
+    lib = _lib.load()
+    ws = _ws(lib.nsgp_rbf_periodic_build_bwd_workspace(batch, n1, n2, D, ref.element_size()), ref.device)
+    _lib.call(f'nsgp_rbf_periodic_build_bwd_{_sfx(ref)}', _p(x1), _p(x2), _p(ls_rbf), _p(ls_per), _p(period), _p(os_),
+              batch, n1, n2, D, sx1, sx2, _p(G), n2, n1 * n2, _p(g_x1), _p(g_x2), _p(g_lr), _p(g_lp), _p(g_pe), _p(g_os),
+              _p(ws), ws.numel(), _stream())
+    return g_x1, g_x2, g_lr, g_lp, g_pe, g_os
+
+
+# --------------------------------------------------------------------------------------------
 # K3 Paciorek-Schervish (D = 2)
 # --------------------------------------------------------------------------------------------
 def _ps_args(x1, x2, s1, s2):
@@ -586,6 +646,33 @@ class RbfKernelFn(torch.autograd.Function):
         return (g_x1 if n1g else None, g_x2 if n2g else None, g_ls.reshape(ls.shape), g_os.reshape(os_.shape), None)
 
 
+class RbfPeriodicKernelFn(torch.autograd.Function):
+    """K[b] = os[b] RBF-ARD(x; ls_rbf[b]) Periodic(x; ls_per[b], period[b]) + diag_add I; ls_rbf / os may be None
+    (gpytorch ScaleKernel(RBFKernel * PeriodicKernel), models/spatio_temporal_models.py:22,42)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, ls_rbf, ls_per, period, os_, diag_add):
+        ctx.save_for_backward(x1, x2, ls_per, period, *([ls_rbf] if ls_rbf is not None else []),
+                              *([os_] if os_ is not None else []))
+        ctx.has = (ls_rbf is not None, os_ is not None)
+        return rbf_periodic_build(x1, x2, ls_rbf, ls_per, period, os_, diag_add)
+
+    @staticmethod
+    def backward(ctx, G):
+        x1, x2, ls_per, period, *rest = ctx.saved_tensors
+        ls_rbf = rest.pop(0) if ctx.has[0] else None
+        os_ = rest.pop(0) if ctx.has[1] else None
+        n1g, n2g = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g_x1, g_x2, g_lr, g_lp, g_pe, g_os = rbf_periodic_build_bwd(x1, x2, ls_rbf, ls_per, period, os_, G, n1g, n2g)
+        if n1g and x1.dim() == 2:
+            g_x1 = g_x1.sum(0)
+        if n2g and x2.dim() == 2:
+            g_x2 = g_x2.sum(0)
+        return (g_x1 if n1g else None, g_x2 if n2g else None,
+                g_lr.reshape(ls_rbf.shape) if ls_rbf is not None else None, g_lp.reshape(ls_per.shape),
+                g_pe.reshape(period.shape), g_os.reshape(os_.shape) if os_ is not None else None, None)
+
+
 class Ps2dKernelFn(torch.autograd.Function):
     """Paciorek-Schervish kernel for per-point 2x2 matrices (models/multivariate_gibbs_kernel.py:98-150)."""
 
@@ -686,6 +773,11 @@ def gibbs_kernel(x1, x2, ell1, ell2, outputscale=None, diag_add=None):
 def rbf_kernel(x1, x2, ls, os_, diag_add=0.0):
     """Batched: returns (batch, n1, n2); ls:(batch,D) os:(batch,)."""
     return RbfKernelFn.apply(x1, x2, ls, os_, diag_add)
+
+
+def rbf_periodic_kernel(x1, x2, ls_rbf, ls_per, period, os_=None, diag_add=0.0):
+    """Batched (batch, n1, n2): os * RBF-ARD(ls_rbf) * Periodic(ls_per, period); ls_rbf / os_ None = factor absent."""
+    return RbfPeriodicKernelFn.apply(x1, x2, ls_rbf, ls_per, period, os_, diag_add)
 
 
 def ps2d_kernel(x1, x2, s1, s2, jitter=1e-5):

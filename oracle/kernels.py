@@ -57,9 +57,16 @@ def rbf_ard(x1, x2, lengthscale, outputscale=None):
 
 
 def periodic(x1, x2, lengthscale, period):
-    """gpytorch PeriodicKernel (<1.9, recalled): exp(-2 * sum_d sin^2(pi (x-x')/p) / ell)."""
-    diff = math.pi * (x1.unsqueeze(-2) - x2.unsqueeze(-3)) / period
-    return torch.exp(-2.0 * diff.sin().pow(2).sum(-1) / lengthscale)
+    """gpytorch PeriodicKernel, pre-ARD form (< 1.6, recalled; the reference pins no version):
+    exp(-2 sin^2(pi |x/p - x'/p|_2) / ell) -- Euclidean distance of the period-scaled inputs, division by the
+    lengthscale (not its square).  The reference only uses it on one column (active_dims=0:
+    models/spatio_temporal_models.py:22,42, experiments/temporal_exp.py:39), where the later per-dimension
+    form coincides with this one up to the ell vs ell^2 convention.  Parity unpinned."""
+    diff = (x1 / period).unsqueeze(-2) - (x2 / period).unsqueeze(-3)      # period: scalar or (..., 1, 1)
+    r2 = diff.pow(2).sum(-1)
+    pos = r2 > 0                                       # sqrt has an infinite slope at 0; sin^2 has zero slope there
+    r = torch.where(pos, torch.where(pos, r2, torch.ones_like(r2)).sqrt(), torch.zeros_like(r2))
+    return torch.exp(-2.0 * torch.sin(math.pi * r).pow(2) / lengthscale)
 
 
 def softplus(x):
