@@ -395,3 +395,36 @@ def test_matrix_normal_prior_vec_orders_preserved():
     ref = torch.distributions.MultivariateNormal(
         pr.vec_loc, covariance_matrix=pr.kron_cov).log_prob(H.T.flatten())
     assert abs(float(pr.log_prob(H) - ref)) < 1e-8
+
+
+def test_periodic_kernel_known_answers_and_spatiotemporal_restatement():
+    """oracle.kernels.periodic (gpytorch's pre-ARD PeriodicKernel as recalled: division by ell, not ell^2) equals
+    scikit-learn's ExpSineSquared with length_scale = sqrt(ell); it is periodic in the period; the spatio-temporal
+    exact-GP log marginal likelihood of oracle.spatiotemporal equals scipy's multivariate-normal log-density under
+    the same composite kernel assembled from scikit-learn kernels; torch.autograd.gradcheck passes.  (Formula pins only: gpytorch itself is absent.)"""
+    from sklearn.gaussian_process.kernels import RBF, ConstantKernel, ExpSineSquared
+    from oracle import kernels, spatiotemporal as st
+    g = torch.Generator().manual_seed(3)
+    t = torch.randn(40, 1, generator=g, dtype=torch.float64)
+    ell, per = torch.tensor(0.7, dtype=torch.float64), torch.tensor(1.3, dtype=torch.float64)
+    K = kernels.periodic(t, t, ell, per)
+    K_sk = ExpSineSquared(length_scale=float(ell) ** 0.5, periodicity=float(per))(t.numpy())
+    assert np.allclose(K.numpy(), K_sk, rtol=1e-12, atol=1e-12)
+    assert torch.allclose(torch.diagonal(kernels.periodic(t, t + per, ell, per)), torch.ones(40, dtype=torch.float64), atol=1e-12)
+    x = torch.randn(30, 3, generator=g, dtype=torch.float64)
+    y = torch.randn(30, generator=g, dtype=torch.float64)
+    f64 = lambda v: torch.tensor(v, dtype=torch.float64)
+    p = dict(os_t=f64(7.5), ls_t=f64(0.9), ls_p=f64(0.6), period=f64(1.1), os_s=f64(0.8), ls_s=f64([0.7, 0.7]))
+    noise = 0.2
+    # scikit-learn kernels act on all columns; restrict by giving the unused columns a huge lengthscale / period
+    kt = ConstantKernel(7.5) * RBF([0.9, 1e9, 1e9])
+    Kt = kt(x.numpy()) * ExpSineSquared(length_scale=0.6 ** 0.5, periodicity=1.1)(x[:, :1].numpy())
+    Ks = (ConstantKernel(0.8) * RBF([1e9, 0.7, 0.7]))(x.numpy())
+    K_ref = Kt + Ks
+    assert np.allclose(st.st_kernel(x, x, p).numpy(), K_ref, rtol=1e-9, atol=1e-10)
+    from scipy.stats import multivariate_normal
+    lml = multivariate_normal(np.zeros(30), K_ref + noise * np.eye(30)).logpdf(y.numpy())
+    assert abs(float(st.st_exact_mll(x, y, p, noise)) * 30 - lml) < 1e-8
+    leaves = [v.clone().requires_grad_() for v in (p['ls_t'], p['ls_p'], p['period'])]
+    assert torch.autograd.gradcheck(
+        lambda a, b, c: st.st_exact_mll(x, y, dict(p, ls_t=a, ls_p=b, period=c), noise), leaves, atol=1e-6)
