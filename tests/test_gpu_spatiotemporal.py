@@ -202,3 +202,72 @@ def test_sparse_nonstationary_spatiotemporal_trains_and_predicts():
         f = model.predict(xte.double().cuda())
     assert torch.allclose(f.loc.cpu(), mean_ref, rtol=1e-6, atol=1e-6)
     assert torch.allclose(f.covariance_matrix.cpu(), cov_ref, rtol=1e-5, atol=1e-4 * float(cov_ref.abs().max()))
+
+
+def test_khyber_temporal_rbf_times_periodic_exact_gp_matches_oracle():
+    """BASELINE configs[0] with the reference's own model for it: experiments/temporal_exp.py:34-44
+    KhyberTemporalStat = ExactGP(ConstantMean, ScaleKernel(RBFKernel() * PeriodicKernel(), outputscale > 7)) on
+    khyber_time_series.csv (first 80 % train, no shuffle, :59-67; Box-Cox targets).  Objective, gradients and
+    eval-mode predictions against the CPU oracle (float64)."""
+    _need_gpu()
+    import scipy.stats
+    import nsgp.gp as gpytorch
+    from nsgp.gp.constraints import GreaterThan
+    from nsgp.gp.kernels import PeriodicKernel, RBFKernel, ScaleKernel
+    from oracle import kernels
+    from oracle.exact import mvn_log_prob
+    d = pd.read_csv(os.path.join(ROOT, 'tests', 'golden', 'data', 'khyber_time_series.csv'))
+    x = torch.tensor(np.array(d)[:, 0], dtype=F64)
+    y = torch.tensor(scipy.stats.boxcox(np.array(d)[:, -1])[0], dtype=F64)
+    stdx, meanx = torch.std_mean(x)
+    xn = (x - meanx) / stdx
+    k = math.ceil(0.8 * y.shape[0])
+    xtr, ytr, xte = xn[:k], y[:k], xn[k:]
+
+    class KhyberTemporalStat(gpytorch.models.ExactGP):
+        def __init__(self, train_x, train_y, likelihood):
+            super().__init__(train_x, train_y, likelihood)
+            self.mean_module = gpytorch.means.ConstantMean()
+            self.covar_module = ScaleKernel(RBFKernel() * PeriodicKernel(), outputscale_constraint=GreaterThan(7))
+
+        def forward(self, x):
+            return gpytorch.distributions.MultivariateNormal(self.mean_module(x), self.covar_module(x))
+
+    lik = gpytorch.likelihoods.GaussianLikelihood()
+    model = KhyberTemporalStat(xtr, ytr, lik).double().cuda()
+    g = torch.Generator().manual_seed(8)
+    with torch.no_grad():
+        for p_ in model.parameters():
+            p_.add_(0.25 * torch.randn(p_.shape, generator=g, dtype=F64).to(p_))
+    model.train(); lik.train()
+    mll = gpytorch.mlls.ExactMarginalLogLikelihood(lik, model)
+    val = mll(model(model.train_inputs[0]), model.train_targets)
+    val.backward()
+    sp = torch.nn.functional.softplus
+    raw = dict(os=model.covar_module.raw_outputscale, lr=model.covar_module.base_kernel.kernels[0].raw_lengthscale,
+               lp=model.covar_module.base_kernel.kernels[1].raw_lengthscale,
+               pe=model.covar_module.base_kernel.kernels[1].raw_period_length, c=model.mean_module.constant,
+               noise=lik.noise_covar.raw_noise)
+    lv = {k_: v.detach().cpu().double().clone().requires_grad_() for k_, v in raw.items()}
+
+    def kern(a, b):
+        a, b = a.unsqueeze(-1), b.unsqueeze(-1)
+        return (sp(lv['os']) + 7.0) * kernels.rbf_ard(a, b, sp(lv['lr']).reshape(1, 1)) * \
+            kernels.periodic(a, b, sp(lv['lp']).reshape(()), sp(lv['pe']).reshape(()))
+    noise = sp(lv['noise']).reshape(()) + 1e-4
+    n = xtr.shape[0]
+    mean = lv['c'].reshape(()).expand(n)
+    ref = mvn_log_prob(ytr, mean, kern(xtr, xtr) + noise * torch.eye(n, dtype=F64)) / n
+    ref.backward()
+    assert abs(float(val) - float(ref)) < 1e-9 * abs(float(ref)) + 1e-10
+    for k_, v in raw.items():
+        assert torch.allclose(v.grad.detach().cpu().double().reshape(-1), lv[k_].grad.reshape(-1), rtol=1e-6, atol=1e-8), k_
+    model.eval(); lik.eval()
+    with torch.no_grad():
+        pred = lik(model(xte.cuda()))
+        Kxx = kern(xtr, xtr) + noise * torch.eye(n, dtype=F64)
+        Ksx = kern(xte, xtr)
+        m_ref = lv['c'].reshape(()) + Ksx @ torch.linalg.solve(Kxx, ytr - mean)
+        v_ref = torch.diagonal(kern(xte, xte) - Ksx @ torch.linalg.solve(Kxx, Ksx.T)) + noise
+    assert torch.allclose(pred.loc.cpu(), m_ref, rtol=1e-7, atol=1e-8)
+    assert torch.allclose(torch.diagonal(pred.covariance_matrix).cpu(), v_ref, rtol=1e-6, atol=1e-8)
