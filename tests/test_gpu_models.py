@@ -271,3 +271,44 @@ def test_multivariate_gibbs_kernels_match_oracle(data_dir):
     assert torch.allclose(Kn.cpu().double(), refn, rtol=5e-3, atol=5e-3)
     prior_lp = ks.prior_H.log_prob(ks.H)
     assert torch.isfinite(prior_lp)
+
+
+def test_sparse_multivariate_gibbs_kernel_at_baseline_config_size(data_dir):
+    """BASELINE configs[2]: SparseMultivariateGibbsKernel with M=512 inducing points on the 5,676 rows of
+    uib_spatio_temporal.csv (kernel on (lon, lat)).  Size-independent properties of the full
+    5676 x 5676 matrix (the oracle's (N,N,2,2) temporaries would need 6 x 1 GB): symmetry, unit-bounded entries with
+    a unit diagonal, rows of equal locations identical, positive semi-definiteness on a sampled principal block, and
+    agreement with the oracle on a 300-point principal sub-block."""
+    _need_gpu()
+    import pandas as pd
+    from sklearn.cluster import KMeans
+    from models.sparse_multivariate_gibbs_kernel import SparseMultivariateGibbsKernel
+    from oracle import psgibbs
+    d = pd.read_csv(os.path.join(data_dir, 'uib_spatio_temporal.csv'))
+    xy = torch.tensor(d[['lon', 'lat']].values, dtype=torch.float32)
+    std, mean = torch.std_mean(xy, dim=0)
+    x = ((xy - mean) / std).cuda()
+    assert x.shape == (5676, 2)
+    Z = torch.tensor(KMeans(512, n_init=1, random_state=173).fit(x.cpu().numpy()).cluster_centers_,
+                     dtype=torch.float32).cuda()
+    # only 43 distinct cells exist in this CSV: k-means returns duplicate centres; jitter them like a user would
+    Z = Z + 1e-2 * torch.randn(Z.shape, generator=torch.Generator().manual_seed(0)).cuda()
+    torch.manual_seed(0)
+    k = SparseMultivariateGibbsKernel(Z, 2, Z.clone())
+    with torch.no_grad():
+        K = k(x).evaluate()
+    assert K.shape == (5676, 5676)
+    assert float((K - K.t()).abs().max()) < 1e-5
+    assert float(K.max()) <= 1.0 + 1e-4 and float(K.min()) >= -1e-6
+    assert torch.allclose(torch.diagonal(K), torch.ones(5676, device='cuda'), atol=2e-4)
+    same = (x[0] == x).all(-1).nonzero().flatten()                  # the same grid cell at every month
+    assert len(same) == 132 and torch.allclose(K[same[0]], K[same[5]], atol=1e-6)
+    idx = torch.randperm(5676, generator=torch.Generator().manual_seed(1))[:300].cuda()
+    sub = K[idx][:, idx].double().cpu()
+    ev = torch.linalg.eigvalsh(sub)
+    assert float(ev.min()) > -1e-3 * float(ev.max())
+    ls = torch.full((1, 2), math.log(2.0), dtype=F64)
+    xd = x[idx].cpu().double()
+    ref = psgibbs.mv_gibbs_forward(xd, xd, Z.cpu().double(), k.H.detach().cpu().double(), k.D.detach().cpu().double(),
+                                   ls, torch.eye(2, dtype=F64), row_os=math.log(2.0))
+    assert torch.allclose(sub, ref, rtol=5e-3, atol=5e-3)
