@@ -185,28 +185,33 @@ template <typename T> __device__ __forceinline__ void invert_subblock(const T* S
 // (MFMA updates, multiplication by the 16x16 inverses).  The slab's global loads are issued before the
 // factorisation so their latency is hidden.  Block 0 publishes L11 to the side buffer (other workgroups
 // still read A11); potrf_finalize_kernel copies the factors into place at the end.
+// `pre`: the rank-64 update of the PREVIOUS panel (columns [j0-64, j0)) has not been applied to this block column
+// yet; the workgroup applies it to its own diagonal block and slab first (two 64x64x64 MFMA products on blocks
+// that are loaded together with everything else), so that the previous panel's update of the REST of the
+// trailing matrix can run concurrently in the same launch (potrf_step_kernel).
 template <typename T>
-__global__ __launch_bounds__(256) void potrf_panel_kernel(T* __restrict__ A, int64_t n, int64_t lda, int64_t sA,
-                                                          int64_t j0, T* __restrict__ wsL, int64_t npanels,
-                                                          int32_t* __restrict__ info) {
+__device__ __forceinline__ void panel_body(unsigned char* panel_smem, T* __restrict__ A, int64_t n, int64_t lda,
+                                           int64_t sA, int64_t j0, T* __restrict__ wsL, int64_t npanels,
+                                           int32_t* __restrict__ info, int64_t blk, int64_t b, bool pre) {
     typedef Mma16<T> MM;
     typedef typename MM::acc_t acc_t;
-    extern __shared__ __attribute__((aligned(16))) unsigned char panel_smem[];
     T* S = reinterpret_cast<T*>(panel_smem);            // [64][LDD]   diagonal block -> L11
     T* Xs = S + NB * LDD;                               // [64][LDD]   this workgroup's slab
     T* Dinv = Xs + NB * LDD;                            // [4][16][LDI] inverses of the 16x16 diagonal sub-blocks
     T* rd = Dinv + 4 * SB * LDI;                        // [64] reciprocal pivots
+    T* Ps = rd + NB;                                    // [64][LDD]   previous panel's L, diagonal-block rows
+    T* Qs = Ps + NB * LDD;                              // [64][LDD]   previous panel's L, slab rows
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int64_t b = blockIdx.y;
     T* Ab = A + b * sA;
     const int64_t pj = j0 / NB;
-    const int64_t r0 = j0 + NB + (int64_t)blockIdx.x * NB;
+    const int64_t r0 = j0 + NB + blk * NB;
     const int rows = r0 >= n ? 0 : (int)((n - r0) < NB ? (n - r0) : NB);
-    // global -> LDS: wave w takes rows [16w, 16w+16) of both blocks, one coalesced 64-element row per
+    const int fm = lane & 15, fk = lane >> 4;            // MFMA operand lane -> (m|n, k)
+    // global -> LDS: wave w takes rows [16w, 16w+16) of every block, one coalesced 64-element row per
     // instruction; the slab rows stay in registers until the factorisation is done.
     T xr[SB];
     {
-        T dr[SB];                                        // loads first, LDS stores after (one exposed latency)
+        T dr[SB], pr[SB], qr[SB];                        // loads first, LDS stores after (one exposed latency)
 #pragma unroll
         for (int i = 0; i < SB; ++i) dr[i] = Ab[(j0 + w * SB + i) * lda + j0 + lane];
 #pragma unroll
@@ -214,17 +219,50 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(T* __restrict__ A, int
             const int64_t rr = r0 + w * SB + i;
             xr[i] = Ab[(rr < n ? rr : n - 1) * lda + j0 + lane];
         }
+        if (pre) {
+#pragma unroll
+            for (int i = 0; i < SB; ++i) {
+                const int64_t rr = r0 + w * SB + i;
+                pr[i] = Ab[(j0 + w * SB + i) * lda + j0 - NB + lane];
+                qr[i] = Ab[(rr < n ? rr : n - 1) * lda + j0 - NB + lane];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < SB; ++i) { keep(dr[i]); keep(xr[i]); }
+        if (pre) {
+#pragma unroll
+            for (int i = 0; i < SB; ++i) { keep(pr[i]); keep(qr[i]); }
+        }
 #pragma unroll
         for (int i = 0; i < SB; ++i) {
             S[(w * SB + i) * LDD + lane] = dr[i];
             xr[i] = (w * SB + i) < rows ? xr[i] : T(0);
+            if (pre) {
+                Ps[(w * SB + i) * LDD + lane] = pr[i];
+                Qs[(w * SB + i) * LDD + lane] = (w * SB + i) < rows ? qr[i] : T(0);
+            }
         }
     }
     __syncthreads();
+    if (pre) {                                           // S -= P P^T : wave w owns rows [16w, 16w+16)
+        acc_t acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[t][r] = S[(w * SB + MM::crow(r, lane)) * LDD + t * SB + fm];
+#pragma unroll
+        for (int kk = 0; kk < NB / 4; ++kk) {
+            const T av = -Ps[(w * SB + fm) * LDD + 4 * kk + fk];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = MM::mma(av, Ps[(t * SB + fm) * LDD + 4 * kk + fk], acc[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[(w * SB + MM::crow(r, lane)) * LDD + t * SB + fm] = acc[t][r];
+        __syncthreads();
+    }
 
-    const int fm = lane & 15, fk = lane >> 4;            // MFMA operand lane -> (m|n, k)
     int bad = 0;
 #define NSGP_SUBPANEL(C0)                                                                             \
     {                                                                                                 \
@@ -260,8 +298,26 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(T* __restrict__ A, int
 #pragma unroll
     for (int i = 0; i < SB; ++i) Xs[(w * SB + i) * LDD + lane] = xr[i];
     __syncthreads();
+    if (pre && rows > 0) {                               // X -= Q P^T on this wave's strip (rows stay wave-private)
+        acc_t acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[t][r] = Xs[(w * SB + MM::crow(r, lane)) * LDD + t * SB + fm];
+#pragma unroll
+        for (int kk = 0; kk < NB / 4; ++kk) {
+            const T av = -Qs[(w * SB + fm) * LDD + 4 * kk + fk];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = MM::mma(av, Ps[(t * SB + fm) * LDD + 4 * kk + fk], acc[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Xs[(w * SB + MM::crow(r, lane)) * LDD + t * SB + fm] = acc[t][r];
+    }
+    __syncthreads();
 
-    if (blockIdx.x == 0) {
+    if (blk == 0) {
         T* dst = wsL + (b * npanels + pj) * NB * NB;
 #pragma unroll
         for (int i = 0; i < SB; ++i) dst[(w * SB + i) * NB + lane] = S[(w * SB + i) * LDD + lane];
@@ -310,20 +366,19 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(T* __restrict__ A, int
 // latency), then 16 MFMA k-steps per 16x16 tile.  The generic GEMM pays a load latency per BK=16 K-tile
 // (13 us for this shape); this kernel takes ~5 us, which matters because it sits on the serial panel chain.
 template <typename T>
-__global__ __launch_bounds__(256) void potrf_syrk64_kernel(T* __restrict__ A, int64_t n, int64_t lda, int64_t sA,
-                                                           int64_t j0, int64_t wcols) {
+__device__ __forceinline__ void syrk_body(unsigned char* panel_smem, T* __restrict__ A, int64_t n, int64_t lda,
+                                          int64_t sA, int64_t j0, int64_t base, int64_t wcols, int64_t lin, int64_t b) {
+    // j0: first of the 64 K columns (the factored panel); base: first row / column of the updated block
     typedef Mma16<T> MM;
     typedef typename MM::acc_t acc_t;
-    extern __shared__ __attribute__((aligned(16))) unsigned char panel_smem[];
     T* As = reinterpret_cast<T*>(panel_smem);           // [64][LDD]  L21 rows of the tile's row block
     T* Bs = As + NB * LDD;                              // [64][LDD]  L21 rows of the tile's column block
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int fm = lane & 15, fk = lane >> 4;
-    T* Ab = A + (int64_t)blockIdx.y * sA;
-    const int64_t base = j0 + NB;                       // first row / column of the trailing block
+    T* Ab = A + b * sA;
     const int64_t tn = (wcols + NB - 1) / NB;           // tile columns
     // compact enumeration of the lower tiles: rows 0..tn-1 form a triangle, the rest are full
-    const int64_t lin = blockIdx.x, tri = tn * (tn + 1) / 2;
+    const int64_t tri = tn * (tn + 1) / 2;
     int64_t ti, tj;
     if (lin < tri) {
         int64_t r = (int64_t)((sqrtf(8.0f * (float)lin + 1.0f) - 1.0f) * 0.5f);
@@ -387,11 +442,26 @@ __global__ __launch_bounds__(256) void potrf_syrk64_kernel(T* __restrict__ A, in
         }
 }
 
+// One launch per panel.  Workgroups [0, nslab): panel j0 (factor + slabs), applying the previous panel's rank-64
+// update to their own block column first when `pre`.  Workgroups [nslab, ...): the previous panel's rank-64 update
+// of the rest of the trailing block (columns [j0+64, j0+64+wcols)).  The two groups touch disjoint data, so the
+// serial chain per panel is ONE kernel (the bulk update overlaps the next factorisation: look-ahead of depth 1).
+template <typename T>
+__global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ A, int64_t n, int64_t lda, int64_t sA,
+                                                         int64_t j0, T* __restrict__ wsL, int64_t npanels,
+                                                         int32_t* __restrict__ info, int64_t nslab, int pre,
+                                                         int64_t wcols) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char panel_smem[];
+    const int64_t blk = blockIdx.x, b = blockIdx.y;
+    if (blk < nslab) panel_body<T>(panel_smem, A, n, lda, sA, j0, wsL, npanels, info, blk, b, pre != 0);
+    else syrk_body<T>(panel_smem, A, n, lda, sA, j0 - NB, j0 + NB, wcols, blk - nslab, b);
+}
+
 // LAST, ragged panel (nb < 64, nothing below it), factored in LDS by one wave.
 template <typename T>
 __global__ __launch_bounds__(64) void potrf_tail_kernel(T* __restrict__ A, int64_t n, int64_t lda, int64_t sA,
                                                         int64_t j0, T* __restrict__ wsL, int64_t npanels,
-                                                        int32_t* __restrict__ info) {
+                                                        int32_t* __restrict__ info, int pre) {
     __shared__ T Ls[NB * LDD];
     const int lane = threadIdx.x;
     const int64_t b = blockIdx.y;
@@ -399,7 +469,12 @@ __global__ __launch_bounds__(64) void potrf_tail_kernel(T* __restrict__ A, int64
     const int64_t pj = j0 / NB;
     const int nb = (int)(n - j0);
     if (lane < nb)
-        for (int j = 0; j <= lane; ++j) Ls[lane * LDD + j] = Ab[(j0 + lane) * lda + j0 + j];
+        for (int j = 0; j <= lane; ++j) {
+            T v = Ab[(j0 + lane) * lda + j0 + j];
+            if (pre)                                     // pending rank-64 update of the previous panel
+                for (int k = 0; k < NB; ++k) v -= Ab[(j0 + lane) * lda + j0 - NB + k] * Ab[(j0 + j) * lda + j0 - NB + k];
+            Ls[lane * LDD + j] = v;
+        }
     const int bad = factor_lds(Ls, nb, lane);
     T* dst = wsL + (b * npanels + pj) * NB * NB;
     if (lane < nb)
@@ -441,16 +516,12 @@ int potrf_impl(T* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int32_t*
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(info, 0, sizeof(int32_t) * batch, st);
     if (e != hipSuccess) return (int)e;
-    const size_t panel_lds = (2 * (size_t)NB * LDD + 4 * SB * LDI + NB) * sizeof(T);
-    const size_t syrk_lds = 2 * (size_t)NB * LDD * sizeof(T);
-    static bool attr_set = false;       // idempotent attributes, set once per process and type
+    const size_t step_lds = (4 * (size_t)NB * LDD + 4 * SB * LDI + NB) * sizeof(T);
+    static bool attr_set = false;       // idempotent attribute, set once per process and type
     if (!attr_set) {
-        if (panel_lds > 65536)
-            (void)hipFuncSetAttribute((const void*)potrf_panel_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)panel_lds);
-        if (syrk_lds > 65536)
-            (void)hipFuncSetAttribute((const void*)potrf_syrk64_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)syrk_lds);
+        if (step_lds > 65536)
+            (void)hipFuncSetAttribute((const void*)potrf_step_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)step_lds);
         attr_set = true;
     }
     // Two-level blocking for large matrices: rank-64 updates stay inside a 256-column outer panel (they are
@@ -461,22 +532,23 @@ int potrf_impl(T* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int32_t*
         const int64_t Jend = (J0 + NB2) < n ? (J0 + NB2) : n;
         for (int64_t j0 = J0; j0 < Jend; j0 += NB) {
             const int64_t nb = (n - j0) < NB ? (n - j0) : NB;
+            const int pre = j0 > J0;                              // previous panel's rank-64 update still pending
             if (nb < NB) {
                 hipLaunchKernelGGL((potrf_tail_kernel<T>), dim3(1, (unsigned)batch), dim3(64), 0, st, A, n, lda, sA,
-                                   j0, wsL, npanels, info);
+                                   j0, wsL, npanels, info, pre);
                 break;
             }
             const int64_t below = n - j0 - nb;
             const int64_t nslab = below > 0 ? cdiv64(below, NB) : 1;
-            hipLaunchKernelGGL((potrf_panel_kernel<T>), dim3((unsigned)nslab, (unsigned)batch), dim3(256), panel_lds,
-                               st, A, n, lda, sA, j0, wsL, npanels, info);
-            const int64_t wcols = Jend - (j0 + nb);               // columns of this outer panel still to update
+            // rest of the previous panel's update: block starting at j0 + 64, columns up to the outer panel's end
+            const int64_t wcols = pre ? Jend - (j0 + nb) : 0;
+            int64_t ntile = 0;
             if (below > 0 && wcols > 0) {
                 const int64_t tm = cdiv64(below, NB), tn = cdiv64(wcols, NB);
-                const int64_t ntile = tn * (tn + 1) / 2 + (tm - tn) * tn;
-                hipLaunchKernelGGL((potrf_syrk64_kernel<T>), dim3((unsigned)ntile, (unsigned)batch), dim3(256),
-                                   syrk_lds, st, A, n, lda, sA, j0, wcols);
+                ntile = tn * (tn + 1) / 2 + (tm - tn) * tn;
             }
+            hipLaunchKernelGGL((potrf_step_kernel<T>), dim3((unsigned)(nslab + ntile), (unsigned)batch), dim3(256),
+                               step_lds, st, A, n, lda, sA, j0, wsL, npanels, info, nslab, pre, wcols);
         }
         if (Jend < n) {
             const int64_t rest = n - Jend, kw = Jend - J0;
