@@ -5,16 +5,18 @@
 // ExactMarginalLogLikelihood / MultivariateNormal.log_prob and torch.triangular_solve(eye, chol)
 // (models/gibbs_kernels.py:203,300).
 //
-// potrf, per 64-column panel j (right-looking):
-//   panel kernel   every workgroup (4 waves) re-factors the 64x64 diagonal block in LDS -- four 16-column
-//                  sub-panels, each factored by one wave in registers, the rest updated with 16x16x4 MFMAs --
-//                  inverts the 16x16 diagonal sub-blocks and solves its own 64-row slab of the panel
-//                  L21 = A21 L11^-T by blocked substitution on the MFMA.  The factor goes to a side buffer
-//                  (other workgroups still read A11); a final kernel copies the factors into place and
-//                  zeroes the strict upper triangle.
-//   trailing       rank-64 update of the lower tiles on a dedicated one-K-step kernel (all loads issued up
-//                  front); for n >= 2048 rank-64 updates stay inside a 256-column outer panel and the rest
-//                  of the trailing matrix is updated once per outer panel (K = 256) on the MFMA GEMM.
+// potrf, per 64-column panel j (right-looking), ONE launch per panel (potrf_step_kernel):
+//   panel workgroups   (4 waves each) apply the PREVIOUS panel's rank-64 update to their own block column, then
+//                  re-factor the 64x64 diagonal block in LDS -- four 16-column sub-panels, each factored by one
+//                  wave in registers, the rest updated with 16x16x4 MFMAs -- invert the 16x16 diagonal sub-blocks
+//                  and solve their own 64-row slab of the panel L21 = A21 L11^-T by blocked substitution on the
+//                  MFMA.  The factor goes to a side buffer (other workgroups still read A11); a final kernel
+//                  copies the factors into place and zeroes the strict upper triangle.
+//   update workgroups  the rest of the previous panel's rank-64 update (columns beyond the current panel): one
+//                  64x64 lower tile each, ONE K step, all loads issued up front.  They touch no data of the panel
+//                  workgroups, so the update overlaps the next factorisation (look-ahead of depth 1).
+//   n >= 2048      rank-64 updates stay inside a 256-column outer panel; the rest of the trailing matrix is
+//                  updated once per outer panel (K = 256) on the MFMA GEMM.
 // trtri: invert the 64x64 diagonal blocks (16x16 substitution + MFMA merges), then merge pairs of blocks
 //   bottom-up, X21 = -B^-1 (C A^-1), every level two batched MFMA GEMMs (log2(n/64) levels).
 #include "common.h"
