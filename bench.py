@@ -175,6 +175,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly (no hipGraph replay)')
+    ap.add_argument('--rank-share', type=int, default=1, metavar='G',
+                    help='analysis only: run ONE rank\'s share of a G-rank job on this GPU (rows [0, 4096/G) of every '
+                         'minibatch, the objective scaled as on rank 0 of G; no collective).  The JSON line is marked '
+                         '"analysis" and is not a result for --gpus G.')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -202,7 +206,8 @@ def main():
     perm = torch.randperm(N_DATA, generator=gperm)
     n_batches = N_DATA // BATCH
     idx = [perm[i * BATCH:(i + 1) * BATCH] for i in range(n_batches)]       # shared shuffled index
-    lo, hi = shard_bounds(BATCH, world, rank)
+    share = max(1, args.rank_share)
+    lo, hi = shard_bounds(BATCH, world * share, rank)             # share > 1: analysis mode (see --rank-share)
     xs = [x_all[i[lo:hi]].to(device) for i in idx]                           # resident in HBM
     ys = [y_all[i[lo:hi]].to(device) for i in idx]
 
@@ -218,7 +223,7 @@ def main():
         eps.start_step(0, row0=lo)
         opt.zero_grad()
         out = model(x_in)
-        loss = -dp_objective(mll, out, y_in, BATCH, world)
+        loss = -dp_objective(mll, out, y_in, BATCH, world * share)
         loss.backward()
         opt.bucket.gather_grads()            # one multi-tensor copy into the flat gradient bucket
         return loss.detach()
@@ -303,6 +308,8 @@ def main():
                                    'fwd+ELBO+bwd+Adam', 'M': M_INDUCING, 'S': S_SAMPLES,
                        'global_batch': BATCH, 'N': N_DATA, 'parallelism': f'dp{world}',
                        'kzz_cholesky_dtype': 'f64', 'hipgraph': bool(use_graph)},
+            **({'analysis': f'one rank\'s share of a {share}-rank job (rows [0, {hi - lo}) of each minibatch), '
+                            'no collective; NOT a --gpus result'} if share > 1 else {}),
             'final_loss': round(final_loss, 5),
             'roofline': {'bound': 'mfma', 'kernel': 'gemm_kernel<float,128,128,*,*> (all f32 GEMM launches of a step)',
                          'achieved': round(achieved, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',

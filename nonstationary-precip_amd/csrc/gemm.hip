@@ -127,7 +127,7 @@ __device__ __forceinline__ Frag4<T> load_operand4(const T* base, int64_t sr, int
 
 // MODE_A / MODE_B: 0 = operand contiguous along k, 1 = contiguous along m (n).
 template <typename T, int BM, int BN, int BK, int MODE_A, int MODE_B, int EPI = 0, int KSC = 0, int PF = 0>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g, T alpha, const T* __restrict__ A,
+__global__ __launch_bounds__(256, (BM == 128 && BN == 64) ? 3 : 2) void gemm_kernel(GemmArgs g, T alpha, const T* __restrict__ A,
                                                    const T* __restrict__ B, T beta, T* __restrict__ C,
                                                    T* __restrict__ slabs, Epi ep) {
     using MF = Mfma<T>;
@@ -507,7 +507,7 @@ __global__ void splitk_reduce_kernel(GemmArgs g, T alpha, const T* __restrict__ 
     *c = s;
 }
 
-struct Plan { int big; int64_t ksplit, kper; };
+struct Plan { int big, narrow; int64_t ksplit, kper; };
 
 static inline int64_t active_tiles(int64_t M, int64_t N, int64_t bm, int flags) {
     const int64_t tm = cdiv64(M, bm), tn = cdiv64(N, bm);
@@ -548,6 +548,12 @@ template <typename T> Plan make_plan(int64_t M, int64_t N, int64_t K, int64_t nb
     if (p.kper < 32) p.kper = 32;
     p.ksplit = cdiv64(K, p.kper);
     if (p.ksplit < 1) p.ksplit = 1;
+    // A triangular A operand makes the work per tile ROW uneven (K range 1/8 .. 8/8 of K at M = 1024).  When the
+    // grid fits one round of the 512 slots, list scheduling cannot balance it: the launch takes as long as its
+    // longest tile (measured: hidden layer, n = 4096 x 2 GPs, 56 % of the balanced time).  128 x 64 tiles double
+    // the tile count at half the work each, so short tiles back-fill behind the long ones.
+    p.narrow = p.big && p.ksplit == 1 && !(flags & NSGP_GEMM_C_LOWER) &&
+               (flags & (NSGP_GEMM_A_LOWER | NSGP_GEMM_A_UPPER)) && tiles_big <= slots;
     return p;
 }
 
@@ -589,7 +595,7 @@ int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam,
     hipStream_t st = (hipStream_t)stream;
     const int64_t bmn = p.big ? 128 : 64;
     g.tiles_m = cdiv64(M, bmn);
-    g.tiles_n = cdiv64(N, bmn);
+    g.tiles_n = cdiv64(N, p.narrow ? 64 : bmn);
     if (g.tiles_m * g.tiles_n > 2147483647LL || nb * g.ksplit > 65535) return -24;
     const int64_t ngrid = (flags & NSGP_GEMM_C_LOWER) ? active_tiles(M, N, bmn, flags) : g.tiles_m * g.tiles_n;
     if ((flags & NSGP_GEMM_C_LOWER) && g.ksplit == 1 && beta == T(0)) {
@@ -609,13 +615,14 @@ int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam,
     const int ekind = ep.kind, eks = ep.ks != nullptr;
     const bool one_round = ngrid * nb * g.ksplit <= 256 * 3;      // f64: latency-bound single-round grids take PF = 1
     if (ekind != 0 && (g.ksplit != 1 || beta != T(0) || (flags & NSGP_GEMM_C_LOWER))) return -30;
-#define NSGP_LAUNCH_X(BMN, MA, MB, EP, KS)                                                                \
+#define NSGP_LAUNCH_X(BMN, MA, MB, EP, KS) NSGP_LAUNCH_XY(BMN, BMN, MA, MB, EP, KS)
+#define NSGP_LAUNCH_XY(BM_, BN_, MA, MB, EP, KS)                                                          \
     do {                                                                                                  \
-        constexpr int BKc = (BMN == 128 ? 32 : 16);                                                       \
+        constexpr int BKc = (BM_ == 128 ? 32 : 16);                                                       \
         constexpr int pa = (MA == 0 && sizeof(T) == 4) ? 1 : Mfma<T>::PAD;                                \
         constexpr int pb = (MB == 0 && sizeof(T) == 4) ? 1 : Mfma<T>::PAD;                                \
-        constexpr size_t lds = 2 * BKc * ((BMN + pa) + (BMN + pb)) * sizeof(T);                           \
-        auto kern = gemm_kernel<T, BMN, BMN, BKc, MA, MB, EP, KS>;                                        \
+        constexpr size_t lds = 2 * BKc * ((BM_ + pa) + (BN_ + pb)) * sizeof(T);                           \
+        auto kern = gemm_kernel<T, BM_, BN_, BKc, MA, MB, EP, KS>;                                        \
         static bool attr_done = false;                                                                    \
         if (!attr_done && lds > 65536) {                                                                  \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -631,7 +638,19 @@ int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam,
         else if (ekind == 0 && eks && g.modeA == 0 && g.modeB == 0) NSGP_LAUNCH_X(BMN, 0, 0, 0, 1);       \
         else return -31;                                                                                  \
     } while (0)
-    if (ekind != 0 || eks) {
+    if (p.narrow) {
+        if constexpr (sizeof(T) == 4) {
+            if (eks) return -31;
+            if (ekind == 1 && g.modeA == 0 && g.modeB == 1) NSGP_LAUNCH_XY(128, 64, 0, 1, 1, 0);
+            else if (ekind == 1 && g.modeA == 1 && g.modeB == 1) NSGP_LAUNCH_XY(128, 64, 1, 1, 1, 0);
+            else if (ekind == 2 && g.modeA == 0 && g.modeB == 1) NSGP_LAUNCH_XY(128, 64, 0, 1, 2, 0);
+            else if (ekind != 0) return -31;
+            else if (g.modeA == 0 && g.modeB == 0) NSGP_LAUNCH_XY(128, 64, 0, 0, 0, 0);
+            else if (g.modeA == 0) NSGP_LAUNCH_XY(128, 64, 0, 1, 0, 0);
+            else if (g.modeB == 0) NSGP_LAUNCH_XY(128, 64, 1, 0, 0, 0);
+            else NSGP_LAUNCH_XY(128, 64, 1, 1, 0, 0);
+        }
+    } else if (ekind != 0 || eks) {
         if (p.big) {
             if constexpr (sizeof(T) == 4) NSGP_LAUNCH_EPI(128);
         } else {
@@ -674,6 +693,7 @@ int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam,
     }
 #undef NSGP_LAUNCH_EPI
 #undef NSGP_LAUNCH_X
+#undef NSGP_LAUNCH_XY
     if (g.ksplit > 1) {
         const int64_t tot = nb * M * N;
         hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, st, g, alpha,
