@@ -82,6 +82,21 @@ def build(device, dp_world):
     return model, mll, opt
 
 
+def gemm_traffic(world, share):
+    """`traffic`: average L2<->fabric bytes per f32 GEMM launch of a step, from the committed rocprofv3 PMC passes of
+    this same single-GPU workload (tools/gemm_traffic.py -> profiles/r01/gemm_traffic.json).  PMC counters cannot be
+    read from inside the process, so this is the recorded measurement, not a live one; null when it does not apply."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01', 'gemm_traffic.json')
+    if world != 1 or share != 1 or not os.path.exists(path):
+        return {'traffic': None}
+    try:
+        d = json.load(open(path))
+        return {'traffic': round(float(d['bytes_per_launch'])), 'traffic_unit': 'bytes per launch (FETCH_SIZE x2 + '
+                'WRITE_SIZE, incl. Infinity-Cache hits)', 'traffic_source': 'profiles/r01/gemm_traffic.json'}
+    except (OSError, ValueError, KeyError):
+        return {'traffic': None}
+
+
 def host_cores():
     """CPU threads this process may actually use: cgroup quota if set, else the affinity mask."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
@@ -313,7 +328,7 @@ def main():
             'final_loss': round(final_loss, 5),
             'roofline': {'bound': 'mfma', 'kernel': 'gemm_kernel<float,128,128,*,*> (all f32 GEMM launches of a step)',
                          'achieved': round(achieved, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
+                         'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), **gemm_traffic(world, share),
                          'gemm_ms_per_step': round(gemm_ms / nprof, 3),
                          'gemm_launches_per_step': gemm_launches // nprof,
                          'algorithmic_gflop_per_step': round(gemm_flops / nprof / 1e9, 2),

@@ -40,8 +40,15 @@ class WhitenFn(torch.autograd.Function):
         z64, off = [], 0
         M = groups[0][0].shape[-2]
         K = torch.empty((sum(g[0].shape[0] for g in groups), M, M), dtype=torch.float64, device=groups[0][0].device)
-        for Z, ls, os_ in groups:                # every group's Gram matrices straight into the batched buffer
-            Zd, lsd, osd = Z.double(), ls.double(), os_.double()
+        # float64 copies of all (small) parameters with ONE multi-tensor copy instead of a cast launch per tensor
+        flat = [t for g in groups for t in g]
+        if all(t.dtype == torch.float64 for t in flat):
+            f64 = list(flat)
+        else:
+            f64 = [torch.empty(t.shape, dtype=torch.float64, device=t.device) for t in flat]
+            torch._foreach_copy_(f64, [t.detach() for t in flat])
+        for gi, (Z, ls, os_) in enumerate(groups):          # Gram matrices straight into the batched buffer
+            Zd, lsd, osd = f64[3 * gi:3 * gi + 3]
             z64.append((Zd, lsd, osd))
             ops.rbf_build(Zd, Zd, lsd, osd, diag_add=jitter, out=K[off:off + Z.shape[0]])
             off += Z.shape[0]
@@ -84,9 +91,15 @@ class WhitenFn(torch.autograd.Function):
             else:
                 Zk, lsk, osk = Zd, lsd, osd
             gZa, gZb, gls, gos = ops.rbf_build_bwd(Zk, Zk, lsk, osk, Kb.contiguous())
-            dt = ctx.dtypes[gi]
-            grads += [(gZa + gZb).to(dt), gls.to(dt), gos.to(dt)]
-        return tuple(grads)
+            grads += [gZa.add_(gZb), gls, gos]
+        # back to the parameters' dtypes with ONE multi-tensor copy
+        outs = [g if g.dtype == ctx.dtypes[i // 3] else torch.empty(g.shape, dtype=ctx.dtypes[i // 3], device=g.device)
+                for i, g in enumerate(grads[2:])]
+        src = [g for g, o in zip(grads[2:], outs) if o is not g]
+        dst = [o for g, o in zip(grads[2:], outs) if o is not g]
+        if dst:
+            torch._foreach_copy_(dst, src)
+        return (None, None, *outs)
 
 
 def whiten(groups, jitter=1e-4, chol_bwd_f64=True):

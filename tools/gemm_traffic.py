@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""L2<->fabric bytes per launch of the DSVI step's f32 GEMM family from two rocprofv3 PMC passes
+(`--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, each with --kernel-trace only) of
+`bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline`.
+
+    python tools/gemm_traffic.py <fetch-pass-dir> <write-pass-dir> > profiles/r01/gemm_traffic.json
+
+FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled (gfx950 counts 64 B per 128-B request on wide streaming
+reads, MI355X_MICROARCH.md) and includes Infinity-Cache hits, so the figure is an upper bound on HBM traffic.
+Only the launches of a DSVI step are counted (grids 655360 / 131072 = n-wide outputs, 129024 = split-K M x M)."""
+import csv
+import glob
+import json
+import os
+import sys
+
+STEP_GRIDS = {'655360', '131072', '129024'}
+
+
+def total(d, counter):
+    tot, n = 0.0, 0
+    for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if 'gemm_kernel<float, 128' in r['Kernel_Name'] and r['Counter_Name'] == counter \
+                    and r.get('Grid_Size', r.get('Grid_Size_X')) in STEP_GRIDS:
+                tot += float(r['Counter_Value']) * 1024.0
+                n += 1
+    return tot, n
+
+
+def main():
+    fetch, nf = total(sys.argv[1], 'FETCH_SIZE')
+    write, nw = total(sys.argv[2], 'WRITE_SIZE')
+    out = {'kernel': 'gemm_kernel<float,128,128|64,...> launches of a DSVI step', 'launches_counted': nf,
+           'fetch_bytes_per_launch_x2': 2.0 * fetch / max(nf, 1), 'write_bytes_per_launch': write / max(nw, 1),
+           'bytes_per_launch': 2.0 * fetch / max(nf, 1) + write / max(nw, 1),
+           'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only); '
+                     'FETCH doubled per the gfx950 correction; counts Infinity-Cache hits'}
+    json.dump(out, sys.stdout, indent=1)
+    print()
+
+
+if __name__ == '__main__':
+    main()
