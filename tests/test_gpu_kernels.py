@@ -447,3 +447,54 @@ def test_cpu_tensors_are_rejected_loudly(ops):
     e = torch.ones(2, 4)
     with pytest.raises(BackendError):
         ops.gibbs_build(x, x, e, e)
+
+
+# ------------------------------------------------------------------------ ABI edge cases
+def test_empty_inputs_are_no_ops_and_bad_arguments_report_their_index(ops):
+    """The C ABI's error convention (include/nsgp.h): 0 = ok, -k = argument k invalid; zero-sized problems return 0
+    without touching memory.  Called straight through ctypes (no Python-side validation in the way)."""
+    import ctypes
+    from nsgp import _lib
+    lib = _lib.load()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    x = torch.randn(4, 2, device='cuda', dtype=F64)
+    ell = torch.rand(2, 4, device='cuda', dtype=F64) + 0.5
+    K = torch.full((4, 4), 7.0, device='cuda', dtype=F64)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    # empty Gibbs build: n1 == 0 or n2 == 0
+    assert lib.nsgp_gibbs_build_fwd_f64(P(x), P(x), P(ell), P(ell), 0, 4, 2, None, None, P(K), 4, st) == 0
+    assert lib.nsgp_gibbs_build_fwd_f64(P(x), P(x), P(ell), P(ell), 4, 0, 2, None, None, P(K), 4, st) == 0
+    torch.cuda.synchronize()
+    assert float(K.min()) == 7.0                                       # untouched
+    # bad arguments: null x1 (arg 1), D = 0 (arg 7), ldk < n2 (arg 11)
+    assert lib.nsgp_gibbs_build_fwd_f64(None, P(x), P(ell), P(ell), 4, 4, 2, None, None, P(K), 4, st) == -1
+    assert lib.nsgp_gibbs_build_fwd_f64(P(x), P(x), P(ell), P(ell), 4, 4, 0, None, None, P(K), 4, st) == -7
+    assert lib.nsgp_gibbs_build_fwd_f64(P(x), P(x), P(ell), P(ell), 4, 4, 2, None, None, P(K), 3, st) == -11
+    # GEMM: M == 0 / N == 0 are no-ops; K == 0 writes beta * C; contradictory triangle flags are rejected
+    A = torch.randn(4, 4, device='cuda', dtype=F32)
+    C = torch.full((4, 4), 3.0, device='cuda', dtype=F32)
+    g = lambda M, N, Kd, beta, flags: lib.nsgp_gemm_f32(M, N, Kd, 1.0, P(A), 4, 1, 0, 0, P(A), 4, 1, 0, 0, beta, P(C), 4, 0, 0,
+                                                       1, 1, flags, None, 0, st)
+    assert g(0, 4, 4, 0.0, 0) == 0 and g(4, 0, 4, 0.0, 0) == 0
+    torch.cuda.synchronize()
+    assert float(C.min()) == 3.0
+    assert g(4, 4, 0, 2.0, 0) == 0
+    torch.cuda.synchronize()
+    assert torch.allclose(C, torch.full_like(C, 6.0))
+    assert g(4, 4, 4, 0.0, ops.GEMM_A_LOWER | ops.GEMM_A_UPPER) == -22
+    assert g(-1, 4, 4, 0.0, 0) == -1
+    # potrf / trtri with n == 0 or batch == 0
+    info = torch.zeros(1, dtype=torch.int32, device='cuda')
+    assert lib.nsgp_potrf_f64(P(K), 0, 4, 16, 1, P(info), None, 0, st) == 0
+    assert lib.nsgp_potrf_f64(P(K), 4, 4, 16, 0, P(info), None, 0, st) == 0
+    assert lib.nsgp_potrf_f64(P(K), 4, 3, 16, 1, P(info), None, 0, st) == -3          # lda < n
+    assert lib.nsgp_potrf_f64(P(K), 4, 4, 16, 1, P(info), None, 0, st) == -7          # workspace missing
+    assert lib.nsgp_trtri_f64(P(K), 0, 4, 16, P(K), 4, 16, 1, None, 0, st) == 0
+    # fused SVGP GEMM: empty batch
+    assert lib.nsgp_svgp_tri_gemm_colstats_f32(P(A), 0, P(A), None, 0, 4, 4, P(C), None, P(C), st) == 0
+    assert lib.nsgp_svgp_tri_gemm_colstats_f32(P(A), 2, P(A), None, 1, 4, 4, P(C), None, P(C), st) == -2   # trans not 0/1
+    # a non-positive-definite matrix is reported LAPACK-style in info (1-based index of the failing minor)
+    Bad = torch.eye(70, device='cuda', dtype=F64)
+    Bad[65, 65] = -1.0
+    L, info = ops.potrf(Bad)
+    assert int(info[0]) == 66
