@@ -190,6 +190,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly (no hipGraph replay)')
+    ap.add_argument('--no-build-chol', action='store_true',
+                    help='skip the Gibbs-build + Cholesky fields (PMC passes of the DSVI step only)')
     ap.add_argument('--rank-share', type=int, default=1, metavar='G',
                     help='analysis only: run ONE rank\'s share of a G-rank job on this GPU (rows [0, 4096/G) of every '
                          'minibatch, the objective scaled as on rank 0 of G; no collective).  The JSON line is marked '
@@ -336,7 +338,8 @@ def main():
                          'f64_gemm_launches_per_step': g64_launches // nprof},
         }
         if world == 1:
-            result.update(gibbs_chol_ms(device))
+            if not args.no_build_chol:
+                result.update(gibbs_chol_ms(device))
             if not args.no_cpu_baseline:
                 torch.set_num_threads(host_cores())
                 v, nsteps = cpu_baseline(x_all, y_all, idx)

@@ -1,28 +1,25 @@
 #!/usr/bin/env python3
 """L2<->fabric bytes per launch of the DSVI step's f32 GEMM family from two rocprofv3 PMC passes
 (`--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, each with --kernel-trace only) of
-`bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline`.
+`bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-build-chol` (every f32 128-row-tile GEMM dispatch of
+such a run belongs to a DSVI step).
 
     python tools/gemm_traffic.py <fetch-pass-dir> <write-pass-dir> > profiles/r01/gemm_traffic.json
 
 FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled (gfx950 counts 64 B per 128-B request on wide streaming
 reads, MI355X_MICROARCH.md) and includes Infinity-Cache hits, so the figure is an upper bound on HBM traffic.
-Only the launches of a DSVI step are counted (grids 655360 / 131072 = n-wide outputs, 129024 = split-K M x M)."""
+"""
 import csv
 import glob
 import json
 import os
 import sys
 
-STEP_GRIDS = {'655360', '131072', '129024'}
-
-
 def total(d, counter):
     tot, n = 0.0, 0
     for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
         for r in csv.DictReader(open(f)):
-            if 'gemm_kernel<float, 128' in r['Kernel_Name'] and r['Counter_Name'] == counter \
-                    and r.get('Grid_Size', r.get('Grid_Size_X')) in STEP_GRIDS:
+            if 'gemm_kernel<float, 128' in r['Kernel_Name'] and r['Counter_Name'] == counter:
                 tot += float(r['Counter_Value']) * 1024.0
                 n += 1
     return tot, n
