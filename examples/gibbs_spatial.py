@@ -18,6 +18,7 @@ kernel; `predict()` (models/nonstationary_models.py:45-62) is the model's own pr
 """
 import argparse
 import math
+import os
 
 import _path  # noqa: F401
 import numpy as np
@@ -29,6 +30,7 @@ import gpytorch                                                  # noqa: E402
 import utils.dataprep as dp                                      # noqa: E402
 from utils.config import BASE_SEED, DATASET_DIR                  # noqa: E402
 from utils.metrics import nlpd, rmse                             # noqa: E402
+from nsgp.harness import fit                                     # noqa: E402
 
 
 def main():
@@ -44,6 +46,8 @@ def main():
     ap.add_argument('--noise', type=float, default=0.011)
     ap.add_argument('--scale', type=float, default=0.644)
     ap.add_argument('--lr', type=float, default=0.01)
+    ap.add_argument('--threshold', type=float, default=0.0, help='stop when |delta loss| falls below this (0: never)')
+    ap.add_argument('--logdir', default=None, help='write log.jsonl / best.tar / final.tar per split here')
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit('examples/gibbs_spatial.py needs the MI355X: nsgp has no CPU path')
@@ -94,16 +98,23 @@ def main():
         likelihood.train()
         optimizer = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=args.lr)
         mll = gpytorch.mlls.ExactMarginalLogLikelihood(likelihood, model)
-        for it in range(args.iters):
-            optimizer.zero_grad()
+
+        def loss_fn():
             with gpytorch.settings.max_cg_iterations(4000):
-                loss = -mll(model(x_train), y_train)
-            loss.backward()
+                return -mll(model(x_train), y_train)
+
+        def progress(it, loss):
             if it % max(1, args.iters // 10) == 0:
-                print(f'  split {i} iter {it + 1}/{args.iters} loss {float(loss):.4f} '
+                print(f'  split {i} iter {it + 1}/{args.iters} loss {loss:.4f} '
                       f'amplitude {float(model.covar_module.outputscale):.3f} noise {float(model.likelihood.noise):.3f}',
                       flush=True)
-            optimizer.step()
+        # run harness of SURVEY 8f.4 (early stop on |delta loss| < threshold, best / final checkpoints, JSON-lines log)
+        res = fit(model, loss_fn, optimizer, max_iters=args.iters, threshold=args.threshold,
+                  logdir=os.path.join(args.logdir, f'split{i}') if args.logdir else None, log_interval=10,
+                  scalars=lambda: {'outputscale': float(model.covar_module.outputscale),
+                                   'noise': float(model.likelihood.noise)}, callback=progress)
+        if res['stopped_early']:
+            print(f"  split {i}: stopped after {res['iterations']} iterations (|delta loss| < {args.threshold:g})")
 
         model.eval()
         likelihood.eval()
