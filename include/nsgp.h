@@ -282,6 +282,28 @@ int nsgp_gauss_ell_fwd_f64(const double* y, const double* mu, const double* v, c
 int nsgp_gauss_ell_bwd_f64(const double* y, const double* mu, const double* v, const double* noise,
                            int64_t S, int64_t n, double scale, const double* gout, double* gmu, double* gv, double* gnoise,
                            void* ws, size_t ws_bytes, void* stream);
+/* Scalar ("total") forms for the fused ELBO tail: one output, one device-resident upstream gradient.
+ *   gauss_ell_total: out[0] = scale * sum_s sum_i E_q log N(y_i | f_si, noise)   (fold 1/S, 1/B, sign into scale);
+ *       backward with gout a 1-element DEVICE scalar (no host round trip, no per-sample gradient vector)
+ *   kl_whitened_total: out[0] = scale * sum_b KL(N(m_b, Lq_b Lq_b^T) || N(0, I));  backward: scale * gout[0] * dKL */
+int nsgp_gauss_ell_total_fwd_f32(const float* y, const float* mu, const float* v, const float* noise, int64_t S,
+                                 int64_t n, float scale, float* out, void* ws, size_t ws_bytes, void* stream);
+int nsgp_gauss_ell_total_fwd_f64(const double* y, const double* mu, const double* v, const double* noise, int64_t S,
+                                 int64_t n, double scale, double* out, void* ws, size_t ws_bytes, void* stream);
+int nsgp_gauss_ell_total_bwd_f32(const float* y, const float* mu, const float* v, const float* noise, int64_t S,
+                                 int64_t n, float scale, const float* gout, float* gmu, float* gv, float* gnoise,
+                                 void* ws, size_t ws_bytes, void* stream);
+int nsgp_gauss_ell_total_bwd_f64(const double* y, const double* mu, const double* v, const double* noise, int64_t S,
+                                 int64_t n, double scale, const double* gout, double* gmu, double* gv, double* gnoise,
+                                 void* ws, size_t ws_bytes, void* stream);
+int nsgp_kl_whitened_total_fwd_f32(const float* m, const float* Lq, int64_t batch, int64_t M, float scale, float* out,
+                                   void* ws, size_t ws_bytes, void* stream);
+int nsgp_kl_whitened_total_fwd_f64(const double* m, const double* Lq, int64_t batch, int64_t M, double scale,
+                                   double* out, void* ws, size_t ws_bytes, void* stream);
+int nsgp_kl_whitened_total_bwd_f32(const float* m, const float* Lq, int64_t batch, int64_t M, float scale,
+                                   const float* gout, float* gm, float* gLq, void* stream);
+int nsgp_kl_whitened_total_bwd_f64(const double* m, const double* Lq, int64_t batch, int64_t M, double scale,
+                                   const double* gout, double* gm, double* gLq, void* stream);
 int nsgp_kl_whitened_fwd_f32(const float* m, const float* Lq, int64_t batch, int64_t M, float* out,
                              void* ws, size_t ws_bytes, void* stream);
 int nsgp_kl_whitened_bwd_f32(const float* m, const float* Lq, int64_t batch, int64_t M, float gout,

@@ -159,13 +159,13 @@ __global__ __launch_bounds__(256) void reduce_final_kernel(const T* __restrict__
 }
 
 // ---- gaussian expected log-likelihood (per sample row s) -------------------------------------------
-// part[s * gridDim.x + blk] = (gout ? gout[s] : 1) * sum over a chunk of row s of
+// part[s * gridDim.x + blk] = (gout ? gout[s * gs] : 1) * sum over a chunk of row s of      (gs = 0: one shared gout)
 //     want_gnoise ? 1/2 (e/s2^2 - 1/s2) : -1/2 (e/s2 + log s2 + log 2pi),  e = (y - mu)^2 + v
 template <typename T>
 __global__ __launch_bounds__(256) void gauss_ell_part_kernel(const T* __restrict__ y, const T* __restrict__ mu,
                                                              const T* __restrict__ v, const T* __restrict__ noise,
-                                                             const T* __restrict__ gout, int64_t n, int want_gnoise,
-                                                             T* __restrict__ part) {
+                                                             const T* __restrict__ gout, int64_t gs, int64_t n,
+                                                             int want_gnoise, T* __restrict__ part) {
     __shared__ T lds[4];
     const int64_t s = blockIdx.y;
     const T s2 = noise[0];
@@ -178,17 +178,17 @@ __global__ __launch_bounds__(256) void gauss_ell_part_kernel(const T* __restrict
         acc += want_gnoise ? T(0.5) * (e * is2 * is2 - is2) : T(-0.5) * (e * is2 + ls2 + l2pi);
     }
     acc = block_sum_256(acc, lds);
-    if (threadIdx.x == 0) part[s * gridDim.x + blockIdx.x] = gout ? gout[s] * acc : acc;
+    if (threadIdx.x == 0) part[s * gridDim.x + blockIdx.x] = gout ? gout[s * gs] * acc : acc;
 }
 
 template <typename T>
 __global__ void gauss_ell_bwd_kernel(const T* __restrict__ y, const T* __restrict__ mu, const T* __restrict__ noise,
-                                     const T* __restrict__ gout, int64_t S, int64_t n, T scale,
+                                     const T* __restrict__ gout, int64_t gs, int64_t S, int64_t n, T scale,
                                      T* __restrict__ gmu, T* __restrict__ gv) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= S * n) return;
     const T is2 = T(1) / noise[0];
-    const T coef = gout[idx / n] * scale;
+    const T coef = gout[(idx / n) * gs] * scale;
     gmu[idx] = coef * (y[idx % n] - mu[idx]) * is2;
     gv[idx] = T(-0.5) * coef * is2;
 }
@@ -216,9 +216,10 @@ __global__ __launch_bounds__(256) void kl_part_kernel(const T* __restrict__ m, c
 
 template <typename T>
 __global__ void kl_bwd_kernel(const T* __restrict__ m, const T* __restrict__ Lq, int64_t batch, int64_t M, T gout,
-                              T* __restrict__ gm, T* __restrict__ gLq) {
+                              const T* __restrict__ gdev, T* __restrict__ gm, T* __restrict__ gLq) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= batch * M * M) return;
+    if (gdev) gout *= gdev[0];                          // upstream gradient read on the device (no host scalar)
     const int64_t e = idx % (M * M), b = idx / (M * M);
     const int64_t i = e / M, j = e % M;
     T g = T(0);
@@ -285,9 +286,11 @@ static inline int64_t gauss_blocks(int64_t n) {
     return nblk;
 }
 
+// `total`: out[0] = scale * sum over ALL samples and points (the caller folds 1/S into scale), one launch less
+// downstream than an (S,) vector followed by a mean; the backward then takes ONE upstream gradient gout[0].
 template <typename T>
 int gauss_fwd_impl(const T* y, const T* mu, const T* v, const T* noise, int64_t S, int64_t n, T scale, T* out,
-                   void* ws, size_t wsb, void* stream) {
+                   void* ws, size_t wsb, void* stream, bool total = false) {
     if (!y) return -1; if (!mu) return -2; if (!v) return -3; if (!noise) return -4;
     if (S < 0 || S > 65535) return -5; if (n < 0) return -6; if (!out) return -8;
     if (S == 0) return 0;
@@ -295,15 +298,20 @@ int gauss_fwd_impl(const T* y, const T* mu, const T* v, const T* noise, int64_t 
     if (!ws || wsb < (size_t)(S * nblk) * sizeof(T)) return -9;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL((gauss_ell_part_kernel<T>), dim3((unsigned)nblk, (unsigned)S), dim3(256), 0, st, y, mu, v, noise,
-                       (const T*)nullptr, n, 0, (T*)ws);
-    hipLaunchKernelGGL((reduce_final_kernel<T>), dim3((unsigned)S), dim3(256), 0, st, (const T*)ws, nblk, S, scale,
-                       T(0), out);
+                       (const T*)nullptr, (int64_t)0, n, 0, (T*)ws);
+    if (total)
+        hipLaunchKernelGGL((reduce_final_kernel<T>), dim3(1), dim3(256), 0, st, (const T*)ws, S * nblk, (int64_t)1, scale,
+                           T(0), out);
+    else
+        hipLaunchKernelGGL((reduce_final_kernel<T>), dim3((unsigned)S), dim3(256), 0, st, (const T*)ws, nblk, S, scale,
+                           T(0), out);
     return nsgp_launch_status();
 }
 
 template <typename T>
 int gauss_bwd_impl(const T* y, const T* mu, const T* v, const T* noise, int64_t S, int64_t n, T scale, const T* gout,
-                   T* gmu, T* gv, T* gnoise, void* ws, size_t wsb, void* stream) {
+                   T* gmu, T* gv, T* gnoise, void* ws, size_t wsb, void* stream, bool total = false) {
+    const int64_t gs = total ? 0 : 1;
     if (!y) return -1; if (!mu) return -2; if (!v) return -3; if (!noise) return -4;
     if (S < 0 || S > 65535) return -5; if (n < 0) return -6; if (!gout) return -8; if (!gmu) return -9;
     if (!gv) return -10;
@@ -311,13 +319,13 @@ int gauss_bwd_impl(const T* y, const T* mu, const T* v, const T* noise, int64_t 
     const int64_t tot = S * n;
     if (tot > 0)
         hipLaunchKernelGGL((gauss_ell_bwd_kernel<T>), dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, st, y, mu, noise,
-                           gout, S, n, scale, gmu, gv);
+                           gout, gs, S, n, scale, gmu, gv);
     if (gnoise) {
         const int64_t nblk = gauss_blocks(n);
         if (!ws || wsb < (size_t)(S * nblk + 1) * sizeof(T)) return -12;
         if (S > 0)
             hipLaunchKernelGGL((gauss_ell_part_kernel<T>), dim3((unsigned)nblk, (unsigned)S), dim3(256), 0, st, y, mu,
-                               v, noise, gout, n, 1, (T*)ws);
+                               v, noise, gout, gs, n, 1, (T*)ws);
         hipLaunchKernelGGL((reduce_final_kernel<T>), dim3(1), dim3(256), 0, st, (const T*)ws, S * nblk, (int64_t)1,
                            scale, T(0), gnoise);
     }
@@ -325,26 +333,32 @@ int gauss_bwd_impl(const T* y, const T* mu, const T* v, const T* noise, int64_t 
 }
 
 template <typename T>
-int kl_fwd_impl(const T* m, const T* Lq, int64_t batch, int64_t M, T* out, void* ws, size_t wsb, void* stream) {
+int kl_fwd_impl(const T* m, const T* Lq, int64_t batch, int64_t M, T* out, void* ws, size_t wsb, void* stream,
+                bool total = false, T scale = T(1)) {
     if (!m) return -1; if (!Lq) return -2; if (batch < 0) return -3; if (M < 0) return -4; if (!out) return -5;
     if (batch == 0) return 0;
     int64_t nblk = cdiv64(M * M, 1024); if (nblk > 256) nblk = 256; if (nblk < 1) nblk = 1;
     if (!ws || wsb < (size_t)(batch * nblk) * sizeof(T)) return -6;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL((kl_part_kernel<T>), dim3((unsigned)nblk, (unsigned)batch), dim3(256), 0, st, m, Lq, M, (T*)ws);
-    hipLaunchKernelGGL((reduce_final_kernel<T>), dim3((unsigned)batch), dim3(256), 0, st, (const T*)ws, nblk, batch,
-                       T(0.5), T(-0.5) * T(M), out);
+    if (total)                                           // out[0] = scale * sum_b KL_b
+        hipLaunchKernelGGL((reduce_final_kernel<T>), dim3(1), dim3(256), 0, st, (const T*)ws, batch * nblk, (int64_t)1,
+                           T(0.5) * scale, T(-0.5) * T(M) * T(batch) * scale, out);
+    else
+        hipLaunchKernelGGL((reduce_final_kernel<T>), dim3((unsigned)batch), dim3(256), 0, st, (const T*)ws, nblk, batch,
+                           T(0.5), T(-0.5) * T(M), out);
     return nsgp_launch_status();
 }
 
 template <typename T>
-int kl_bwd_impl(const T* m, const T* Lq, int64_t batch, int64_t M, T gout, T* gm, T* gLq, void* stream) {
+int kl_bwd_impl(const T* m, const T* Lq, int64_t batch, int64_t M, T gout, T* gm, T* gLq, void* stream,
+                const T* gdev = nullptr) {
     if (!m) return -1; if (!Lq) return -2; if (batch < 0) return -3; if (M < 0) return -4; if (!gm) return -6;
     if (!gLq) return -7;
     const int64_t tot = batch * M * M;
     if (tot == 0) return 0;
     hipLaunchKernelGGL((kl_bwd_kernel<T>), dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, (hipStream_t)stream, m, Lq,
-                       batch, M, gout, gm, gLq);
+                       batch, M, gout, gdev, gm, gLq);
     return nsgp_launch_status();
 }
 
@@ -463,6 +477,45 @@ int nsgp_rowdot_f64(const double* A, const double* g, int64_t batch, int64_t M, 
     hipLaunchKernelGGL((rowdot_kernel<double>), dim3((unsigned)M, (unsigned)batch), dim3(256), 0, (hipStream_t)stream,
                        A, g, M, n, out);
     return nsgp_launch_status();
+}
+
+
+/* scalar forms used by the fused ELBO tail (nsgp.ops.GaussEllTotalFn / KlWhitenedTotalFn) */
+int nsgp_gauss_ell_total_fwd_f32(const float* y, const float* mu, const float* v, const float* noise, int64_t S,
+                                 int64_t n, float scale, float* out, void* ws, size_t wsb, void* stream) {
+    return gauss_fwd_impl<float>(y, mu, v, noise, S, n, scale, out, ws, wsb, stream, true);
+}
+int nsgp_gauss_ell_total_fwd_f64(const double* y, const double* mu, const double* v, const double* noise, int64_t S,
+                                 int64_t n, double scale, double* out, void* ws, size_t wsb, void* stream) {
+    return gauss_fwd_impl<double>(y, mu, v, noise, S, n, scale, out, ws, wsb, stream, true);
+}
+int nsgp_gauss_ell_total_bwd_f32(const float* y, const float* mu, const float* v, const float* noise, int64_t S,
+                                 int64_t n, float scale, const float* gout, float* gmu, float* gv, float* gnoise,
+                                 void* ws, size_t wsb, void* stream) {
+    return gauss_bwd_impl<float>(y, mu, v, noise, S, n, scale, gout, gmu, gv, gnoise, ws, wsb, stream, true);
+}
+int nsgp_gauss_ell_total_bwd_f64(const double* y, const double* mu, const double* v, const double* noise, int64_t S,
+                                 int64_t n, double scale, const double* gout, double* gmu, double* gv, double* gnoise,
+                                 void* ws, size_t wsb, void* stream) {
+    return gauss_bwd_impl<double>(y, mu, v, noise, S, n, scale, gout, gmu, gv, gnoise, ws, wsb, stream, true);
+}
+int nsgp_kl_whitened_total_fwd_f32(const float* m, const float* Lq, int64_t batch, int64_t M, float scale, float* out,
+                                   void* ws, size_t wsb, void* stream) {
+    return kl_fwd_impl<float>(m, Lq, batch, M, out, ws, wsb, stream, true, scale);
+}
+int nsgp_kl_whitened_total_fwd_f64(const double* m, const double* Lq, int64_t batch, int64_t M, double scale,
+                                   double* out, void* ws, size_t wsb, void* stream) {
+    return kl_fwd_impl<double>(m, Lq, batch, M, out, ws, wsb, stream, true, scale);
+}
+int nsgp_kl_whitened_total_bwd_f32(const float* m, const float* Lq, int64_t batch, int64_t M, float scale,
+                                   const float* gout, float* gm, float* gLq, void* stream) {
+    if (!gout) return -6;
+    return kl_bwd_impl<float>(m, Lq, batch, M, scale, gm, gLq, stream, gout);
+}
+int nsgp_kl_whitened_total_bwd_f64(const double* m, const double* Lq, int64_t batch, int64_t M, double scale,
+                                   const double* gout, double* gm, double* gLq, void* stream) {
+    if (!gout) return -6;
+    return kl_bwd_impl<double>(m, Lq, batch, M, scale, gm, gLq, stream, gout);
 }
 
 }  // extern "C"

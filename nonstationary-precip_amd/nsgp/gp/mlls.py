@@ -98,10 +98,45 @@ class VariationalELBO(_ApproximateMarginalLogLikelihood):
         return self.likelihood.expected_log_prob(target, variational_dist_f, **kwargs).sum(-1) / B
 
 
+def fused_dsvi_objective(base, approximate_dist_f, target, ell_scale, kl_scale):
+    """ell_scale * sum_s sum_i E_q log p(y_i | f_si)  -  kl_scale * sum_j KL_j  as ONE scalar with a short launch
+    chain (two reductions per term, device-resident upstream gradients), or None when the fast path does not
+    apply (non-Gaussian likelihood, CPU tensors, priors / added-loss terms, non-whitened strategies).
+    DeepApproximateMLL(VariationalELBO) is the case ell_scale = 1/(B S), kl_scale = beta/num_data; the data-parallel
+    share of nsgp.dist.dp_objective uses 1/(B_global S) and beta/(num_data G)."""
+    if not isinstance(base, VariationalELBO) or not base.combine_terms:
+        return None
+    lik = base.likelihood
+    mean, var = approximate_dist_f.mean, approximate_dist_f.variance
+    if not (isinstance(lik, GaussianLikelihood) and mean.is_cuda and target.dim() == 1 and mean.dim() == 2):
+        return None
+    strategies = getattr(base.model.variational_strategy, 'sub_variational_strategies', None)
+    if strategies is None or any(True for _ in base.model.added_loss_terms()) or any(True for _ in base.named_priors()):
+        return None
+    pairs = []
+    for st in strategies:
+        vd = getattr(st, '_variational_distribution', None)
+        if vd is None or not hasattr(vd, 'chol_variational_covar') or not hasattr(st, 'whiten_group'):
+            return None
+        pairs.append((vd.variational_mean, vd.chol_variational_covar))
+    total = ops.GaussEllTotalFn.apply(target, mean, var, lik.noise, float(ell_scale))
+    for m, Lq in pairs:
+        total = total + ops.KlWhitenedTotalFn.apply(m, Lq, -float(kl_scale))
+    return total
+
+
 class DeepApproximateMLL(MarginalLogLikelihood):
     def __init__(self, base_mll):
         super().__init__(base_mll.likelihood, base_mll.model)
         self.base_mll = base_mll
 
     def forward(self, approximate_dist_f, target, **kwargs):
-        return self.base_mll(approximate_dist_f, target, **kwargs).mean(0)
+        base = self.base_mll
+        if not kwargs and isinstance(base, VariationalELBO):
+            mean = approximate_dist_f.mean
+            if mean.dim() == 2:
+                B, S = mean.shape[-1], mean.shape[0]
+                fused = fused_dsvi_objective(base, approximate_dist_f, target, 1.0 / (B * S), base.beta / base.num_data)
+                if fused is not None:
+                    return fused
+        return base(approximate_dist_f, target, **kwargs).mean(0)

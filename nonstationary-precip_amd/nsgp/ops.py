@@ -816,6 +816,68 @@ class KlWhitenedFn(torch.autograd.Function):
         return gm * g, gL * g
 
 
+class GaussEllTotalFn(torch.autograd.Function):
+    """Scalar  scale * sum_s sum_i E_q log N(y_i | f_si, noise): the (S,) vector of GaussEllFn followed by a
+    mean / scaling, as ONE reduction; its backward reads the upstream gradient on the device."""
+
+    @staticmethod
+    def forward(ctx, y, mu, v, noise, scale):
+        ref = _chk(y, mu, v, noise)
+        y, mu, v = _c(y), _c(mu), _c(v)
+        S, n = mu.shape
+        if y.shape != (n,) or v.shape != mu.shape:
+            raise BackendError('gauss_ell_total: shapes')
+        out = torch.empty(1, dtype=ref.dtype, device=ref.device)
+        ws = _red_ws(ref)
+        _lib.call(f'nsgp_gauss_ell_total_fwd_{_sfx(ref)}', _p(y), _p(mu), _p(v), _p(noise.reshape(1)), S, n, float(scale),
+                  _p(out), _p(ws), ws.numel(), _stream())
+        ctx.save_for_backward(y, mu, v, noise)
+        ctx.scale = float(scale)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        y, mu, v, noise = ctx.saved_tensors
+        S, n = mu.shape
+        gmu, gv = torch.empty_like(mu), torch.empty_like(mu)
+        need_noise = ctx.needs_input_grad[3]
+        gn = torch.empty(1, dtype=mu.dtype, device=mu.device) if need_noise else None
+        ws = _red_ws(mu)
+        _lib.call(f'nsgp_gauss_ell_total_bwd_{_sfx(mu)}', _p(y), _p(mu), _p(v), _p(noise.reshape(1)), S, n, ctx.scale,
+                  _p(_c(g).reshape(1)), _p(gmu), _p(gv), _p(gn), _p(ws), ws.numel(), _stream())
+        return None, gmu, gv, gn.reshape(noise.shape) if gn is not None else None, None
+
+
+class KlWhitenedTotalFn(torch.autograd.Function):
+    """Scalar  scale * sum_b KL(N(m_b, Lq_b Lq_b^T) || N(0, I)); backward reads the upstream gradient on the device."""
+
+    @staticmethod
+    def forward(ctx, m, Lq, scale):
+        ref = _chk(m, Lq)
+        m2, L2 = _c(m), _c(Lq)
+        if m2.dim() == 1:
+            m2, L2 = m2.unsqueeze(0), L2.unsqueeze(0)
+        batch, M = m2.shape
+        if L2.shape != (batch, M, M):
+            raise BackendError('kl_whitened_total: shapes')
+        out = torch.empty(1, dtype=ref.dtype, device=ref.device)
+        ws = _red_ws(ref)
+        _lib.call(f'nsgp_kl_whitened_total_fwd_{_sfx(ref)}', _p(m2), _p(L2), batch, M, float(scale), _p(out), _p(ws),
+                  ws.numel(), _stream())
+        ctx.save_for_backward(m2, L2)
+        ctx.scale, ctx.shapes = float(scale), (m.shape, Lq.shape)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        m2, L2 = ctx.saved_tensors
+        batch, M = m2.shape
+        gm, gL = torch.empty_like(m2), torch.empty_like(L2)
+        _lib.call(f'nsgp_kl_whitened_total_bwd_{_sfx(m2)}', _p(m2), _p(L2), batch, M, ctx.scale, _p(_c(g).reshape(1)),
+                  _p(gm), _p(gL), _stream())
+        return gm.reshape(ctx.shapes[0]), gL.reshape(ctx.shapes[1]), None
+
+
 class DgpSampleFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mean, var, eps):

@@ -498,3 +498,34 @@ def test_empty_inputs_are_no_ops_and_bad_arguments_report_their_index(ops):
     Bad[65, 65] = -1.0
     L, info = ops.potrf(Bad)
     assert int(info[0]) == 66
+
+
+@pytest.mark.parametrize('dt', [F64, F32])
+def test_scalar_total_elbo_terms_match_autograd_of_the_vector_forms(ops, dt):
+    """GaussEllTotalFn / KlWhitenedTotalFn (one scalar, device-resident upstream gradient) against torch autograd of
+    the float64 closed forms, including a non-trivial upstream factor."""
+    g = _g(77)
+    S, n, b, M = 5, 333, 2, 70
+    y = torch.randn(n, generator=g, dtype=F64)
+    mu = torch.randn(S, n, generator=g, dtype=F64)
+    v = torch.rand(S, n, generator=g, dtype=F64) + 0.1
+    noise = torch.tensor([0.37], dtype=F64)
+    m = 0.3 * torch.randn(b, M, generator=g, dtype=F64)
+    Lq = torch.tril(0.1 * torch.randn(b, M, M, generator=g, dtype=F64)) + torch.eye(M, dtype=F64)
+    ref_in = [t.clone().requires_grad_() for t in (mu, v, noise, m, Lq)]
+    mu_r, v_r, n_r, m_r, L_r = ref_in
+    ell = (-0.5 * (((y - mu_r) ** 2 + v_r) / n_r + torch.log(n_r) + math.log(2 * math.pi))).sum()
+    Lt = torch.tril(L_r)
+    kl = 0.5 * ((Lt ** 2).sum() + (m_r ** 2).sum() - b * M - 2 * torch.log(torch.diagonal(Lt, dim1=-1, dim2=-2).abs()).sum())
+    c1, c2 = 1.0 / (S * n), 0.013
+    ref = 3.0 * (c1 * ell - c2 * kl)
+    ref.backward()
+    dev = [t.detach().to(dt).cuda().requires_grad_() for t in (mu, v, noise, m, Lq)]
+    mu_d, v_d, n_d, m_d, L_d = dev
+    out = 3.0 * (ops.GaussEllTotalFn.apply(y.to(dt).cuda(), mu_d, v_d, n_d, c1) + ops.KlWhitenedTotalFn.apply(m_d, L_d, -c2))
+    out.backward()
+    tol = dict(rtol=1e-10, atol=1e-12) if dt == F64 else dict(rtol=2e-4, atol=2e-6)
+    assert abs(float(out) - float(ref)) < (1e-10 if dt == F64 else 2e-4) * abs(float(ref))
+    for got, want in zip(dev, ref_in):
+        w = want.grad if want is not L_r else torch.tril(want.grad)
+        assert torch.allclose(got.grad.cpu().double(), w, **tol), got.shape
