@@ -295,7 +295,10 @@ def main():
             t = torch.tensor([elapsed], device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        final_loss = float(loss.item())
+        loss_total = loss.detach().clone().reshape(1)
+        if world > 1:                                   # the ranks' objectives SUM to the single-GPU loss (nsgp/dist.py)
+            dist.all_reduce(loss_total, op=dist.ReduceOp.SUM)
+        final_loss = float(loss_total.item())
 
         # roofline of the dominant kernel family: re-run the same steps EAGERLY with HIP events around
         # every GEMM launch (kept out of the timed region above)
