@@ -260,14 +260,25 @@ def main():
 
     with settings.num_likelihood_samples(S_SAMPLES), settings.eps_provider(eps):
         use_graph = not args.no_graph
+        x_in.copy_(xs[0]); y_in.copy_(ys[0])
+        with torch.no_grad():
+            model(x_in)                                  # first call draws the N(0, 1e-3^2) variational-mean init
+        dp.broadcast_params()
         if use_graph:
             from nsgp.graph import GraphedCallable
-            x_in.copy_(xs[0]); y_in.copy_(ys[0])
+            p0 = opt.bucket.flat_p.detach().clone()      # graph warm-up / capture runs real steps: undo them below
             if world == 1:
                 g_step = GraphedCallable(whole_step)                 # forward + ELBO + backward + Adam: one graph
             else:
                 g_fb = GraphedCallable(fwd_bwd)                      # all-reduce stays an eager RCCL call
                 g_adam = GraphedCallable(adam_step, warmup=1)
+            # same starting point for every N: initial parameters, zero Adam moments, step counter 0
+            with torch.no_grad():
+                opt.bucket.flat_p.copy_(p0)
+                opt.exp_avg.zero_(); opt.exp_avg_sq.zero_()
+                opt.steps = 0
+                if opt.step_dev is not None:
+                    opt.step_dev.zero_()
 
         def step(k):
             x_in.copy_(xs[k % n_batches]); y_in.copy_(ys[k % n_batches])

@@ -1,0 +1,86 @@
+"""Data-parallel DSVI on the GPU product path: two ranks (gloo rendezvous, both on cuda:0 -- RCCL itself needs one
+GPU per rank and is exercised by the driver's multi-GPU run) train a small DeepGP with the sharded minibatch, the
+Philox noise keyed by global row, the flat-bucket all-reduce and the fused Adam step; the result must equal the
+single-process run on the full minibatch (float32 round-off only).  This is the exactness claim of nsgp/dist.py,
+end to end through the HIP kernels."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _run(rank, world, port, out_path, steps):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, 'nonstationary-precip_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.cuda.set_device(0)
+    if world > 1:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    import models.dgps as m
+    from nsgp.dist import DataParallel, PhiloxEps, dp_objective, shard_bounds
+    from nsgp.gp import settings
+    from nsgp.gp.mlls import DeepApproximateMLL, VariationalELBO
+    from nsgp.optim import FusedAdam
+    torch.manual_seed(11)
+    N, D, M, S, B = 2000, 3, 48, 4, 256
+    model = m.DeepGP(1, (N, D), num_inducing=M).cuda()
+    mll = DeepApproximateMLL(VariationalELBO(model.likelihood, model, N))
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, D, generator=g).cuda()
+    y = torch.randn(B, generator=g).cuda()
+    opt = FusedAdam(model.parameters(), lr=0.01, capturable=True, grads_as_views=False)
+    dp = DataParallel(opt.bucket)
+    dp.broadcast_params()
+    lo, hi = shard_bounds(B, world, rank)
+    eps = PhiloxEps(173, row0=lo, step_dev=opt.step_dev)
+    model.train()
+    losses = []
+    with settings.num_likelihood_samples(S), settings.eps_provider(eps):
+        for _ in range(steps):
+            eps.start_step(0, row0=lo)
+            opt.zero_grad()
+            loss = -dp_objective(mll, model(x[lo:hi]), y[lo:hi], B, world)
+            loss.backward()
+            dp.allreduce_grads()
+            opt.step(gather=False)
+            t = loss.detach().clone().reshape(1)
+            if world > 1:
+                dist.all_reduce(t)
+            losses.append(float(t))
+    if rank == 0:
+        torch.save({'p': opt.bucket.flat_p.detach().cpu(), 'losses': torch.tensor(losses)}, out_path)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_training_equals_single_process(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    steps = 4
+    one, two = str(tmp_path / 'one.pt'), str(tmp_path / 'two.pt')
+    mp.spawn(_run, args=(1, 0, one, steps), nprocs=1, join=True)
+    mp.spawn(_run, args=(2, _free_port(), two, steps), nprocs=2, join=True)
+    a = torch.load(one, weights_only=True)
+    b = torch.load(two, weights_only=True)
+    # the ranks' objectives sum to the single-GPU loss at every step ...
+    assert torch.allclose(a['losses'], b['losses'], rtol=2e-5, atol=1e-6), (a['losses'], b['losses'])
+    # ... and after 4 Adam steps the parameters agree to float32 round-off (Adam's 1/sqrt(v) amplifies tiny
+    # gradient differences on near-zero-gradient entries, hence the absolute tolerance of 0.2 * lr)
+    assert a['losses'][-1] < a['losses'][0]
+    assert float((a['p'] - b['p']).abs().max()) < 2e-3
+    assert float((a['p'] - b['p']).abs().mean()) < 2e-5
