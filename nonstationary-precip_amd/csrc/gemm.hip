@@ -14,7 +14,11 @@
 // along whichever of (m|k) is contiguous, prefetched into registers one K-tile ahead, two LDS
 // buffers, one barrier per K-tile.  Triangular operands skip whole K-tiles and are masked in the
 // diagonal tiles; small outputs with a long inner dimension are split along K into slabs that a
-// second kernel sums in a fixed order (deterministic).
+// second kernel sums in a fixed order (deterministic).  Tiles: 128x128x32 (f32, two workgroups per CU),
+// 128x64x32 (f32, three per CU; single-round launches with a triangular A operand), 64x64x16 (f32 small, f64).
+// Fused variants for the SVGP layer (template parameters EPI / KSC, `struct Epi`): column statistics or the
+// A-adjoint assembled in the epilogue, an operand scaled along k in the loader -- the elementwise passes of
+// VariationalStrategy.forward and of its backward never run as separate kernels.
 #include <cstdlib>
 #include "common.h"
 
