@@ -201,13 +201,13 @@ __global__ __launch_bounds__(256) void kl_part_kernel(const T* __restrict__ m, c
     const int64_t b = blockIdx.y;
     const T* L = Lq + b * M * M;
     T acc = T(0);
-    const int64_t tot = M * M;
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < tot; idx += (int64_t)gridDim.x * 256) {
-        const int64_t i = idx / M, j = idx % M;
-        if (j <= i) {
-            const T l = L[idx];
+    // rows blockIdx.x, blockIdx.x + gridDim.x, ...; only the lower triangle is read (no 64-bit div/mod per element)
+    for (int64_t i = blockIdx.x; i < M; i += gridDim.x) {
+        const T* row = L + i * M;
+        for (int64_t j = threadIdx.x; j <= i; j += 256) {
+            const T l = row[j];
             acc += l * l;
-            if (i == j) acc += m[b * M + i] * m[b * M + i] - T(2) * t_log(l < T(0) ? -l : l);
+            if (j == i) acc += m[b * M + i] * m[b * M + i] - T(2) * t_log(l < T(0) ? -l : l);
         }
     }
     acc = block_sum_256(acc, lds);
