@@ -21,6 +21,8 @@ paths relative to ``/root/reference``):
                      DeepGPLayer / VariationalELBO / DeepApproximateMLL
 * ``psgibbs``     -- ``models/latent_priors.py:27-64``, ``models/multivariate_gibbs_kernel.py:20-150``,
                      ``models/sparse_multivariate_gibbs_kernel.py:20-154``
+* ``spatiotemporal`` -- ``models/spatio_temporal_models.py:17-33`` (RBF x Periodic + spatial RBF, exact and SGPR)
+* ``philox``      -- Philox4x32-10 (Random123 known-answer vectors) for the partition-invariant DSVI noise
 
 PARITY PINNING STATUS
 ---------------------
@@ -36,8 +38,9 @@ fetched; the reference ships **no tests, golden vectors or fixtures** for this p
 * everything that goes through gpytorch is **parity unpinned** by reference artefacts.  It is held
   instead by known-answer identities (constant-lengthscale Gibbs == RBF, SVGP at init == prior,
   Z == X optimal-q SVGP == exact GP, SGPR with Z == X == exact GP), by scikit-learn's
-  ``GaussianProcessRegressor`` and scipy LAPACK for the stationary exact GP, and by
-  ``torch.autograd.gradcheck`` for gradients (tests/test_oracle_*.py).
+  ``GaussianProcessRegressor`` and scipy LAPACK for the stationary exact GP, scikit-learn's
+  ``ExpSineSquared`` for the periodic kernel's functional form (gpytorch's ell-vs-ell^2 convention stays
+  recalled), and by ``torch.autograd.gradcheck`` for gradients (tests/test_oracle.py).
 """
 
-from . import functional, dataprep, kernels, exact, sparse, svgp, psgibbs, philox  # noqa: F401
+from . import functional, dataprep, kernels, exact, sparse, svgp, psgibbs, philox, spatiotemporal  # noqa: F401
