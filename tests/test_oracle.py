@@ -428,3 +428,18 @@ def test_periodic_kernel_known_answers_and_spatiotemporal_restatement():
     leaves = [v.clone().requires_grad_() for v in (p['ls_t'], p['ls_p'], p['period'])]
     assert torch.autograd.gradcheck(
         lambda a, b, c: st.st_exact_mll(x, y, dict(p, ls_t=a, ls_p=b, period=c), noise), leaves, atol=1e-6)
+
+
+def test_oracle_reproduces_its_committed_golden_fixtures():
+    """tests/golden/oracle_cfg2_gibbs.npz / oracle_dgp.npz were written by tests/golden/make_oracle_goldens.py from
+    this oracle; re-deriving them guards the checker against drift between rounds (SURVEY 8c fixtures)."""
+    import importlib.util
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    spec = importlib.util.spec_from_file_location('make_oracle_goldens', os.path.join(here, 'make_oracle_goldens.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for name, fresh in (('oracle_cfg2_gibbs.npz', mod.cfg2()), ('oracle_dgp.npz', mod.dgp())):
+        gold = np.load(os.path.join(here, name))
+        assert set(gold.files) == set(fresh)
+        for k in gold.files:
+            assert np.allclose(np.asarray(fresh[k], dtype=np.float64), gold[k], rtol=1e-9, atol=1e-11), (name, k)
