@@ -113,3 +113,11 @@ class chol_bwd_f64(_feature_flag):
     """Adjoint of the Kzz Cholesky inverse in float64 (on, default: what autograd does in the reference,
     where the factor and the solve are float64) or in float32 (off: 3x less MFMA time)."""
     _state = True
+
+
+class check_variational_cholesky(_feature_flag):
+    """Off (default): the DSVI step never synchronises with the host -- a Kzz that is not positive definite shows up as
+    NaNs in the ELBO (gpytorch would have raised from psd_safe_cholesky after its jitter retries).  On: read the
+    factorisation's LAPACK-style `info` after every whitening chain (one host sync per model call) and raise
+    NotPSDError naming the failing GP and leading minor; meant for debugging, not for graph-captured training."""
+    _state = False

@@ -106,6 +106,14 @@ def whiten(groups, jitter=1e-4, chol_bwd_f64=True):
     """groups: list of (Z:(b,M,D), ls:(b,D), os:(b,)).  Returns (list of W64:(b,M,M) per group, info)."""
     flat = [t for g in groups for t in g]
     *Ws, info = WhitenFn.apply(float(jitter), bool(chol_bwd_f64), *flat)
+    from .gp import settings
+    if settings.check_variational_cholesky.on():
+        bad = info.nonzero()
+        if bad.numel():                                   # host sync: debugging aid only
+            from .gp.utils.cholesky import NotPSDError
+            b = int(bad[0, 0])
+            raise NotPSDError(f'Kzz + {jitter:g} I of GP {b} (of {info.numel()} in the whitening chain) is not positive '
+                              f'definite: leading minor {int(info[b])} failed')
     return list(Ws), info
 
 

@@ -122,3 +122,24 @@ def test_fused_projection_ops_match_dense_formulas(dt, b, M, n):
     assert torch.allclose(Lqbar.cpu().double(), Lqbar_ref, **tolb)
     assert torch.allclose(mbar.cpu().double(), mbar_ref, **tolb)
     assert float(torch.triu(Lqbar, 1).abs().max()) == 0.0 if M > 1 else True
+
+
+def test_non_positive_definite_kzz_is_reported_when_asked():
+    """settings.check_variational_cholesky: duplicate inducing points with zero jitter make Kzz singular; the default
+    path stays sync-free (NaNs), the checked path raises like gpytorch's psd_safe_cholesky would."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from nsgp.gp import settings
+    from nsgp.gp.utils.cholesky import NotPSDError
+    from nsgp.svgp import whiten
+    Z = torch.randn(1, 70, 2, dtype=F32).cuda()
+    Z[0, 69] = Z[0, 3]
+    ls = torch.ones(1, 2, device='cuda')
+    os_ = torch.ones(1, device='cuda')
+    Ws, info = whiten([(Z, ls, os_)], jitter=0.0)
+    assert int(info[0]) > 0                                  # LAPACK-style: first failing leading minor
+    with settings.check_variational_cholesky(True):
+        with pytest.raises(NotPSDError, match='not positive definite'):
+            whiten([(Z, ls, os_)], jitter=0.0)
+        Ws, info = whiten([(Z, ls, os_)], jitter=1e-4)       # the default jitter repairs it
+        assert int(info[0]) == 0
