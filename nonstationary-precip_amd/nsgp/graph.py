@@ -17,7 +17,9 @@ class GraphedCallable:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: API calls of OTHER host threads (e.g. the RCCL watchdog polling events of earlier collectives)
+        # must not invalidate this thread's capture
+        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
             self.out = fn()
 
     def __call__(self):
