@@ -180,7 +180,55 @@ def gibbs_chol_ms(device):
         bytes_ = K.element_size() * (n * n + 2 * 2 * (n + n))
         out[f'gibbs_build_GBs_{tag}'] = round(bytes_ / (out[f'gibbs_build_ms_{tag}'] * 1e-3) / 1e9, 1)
         out[f'potrf_TFLOPs_{tag}'] = round(n ** 3 / 3 / (out[f'potrf_ms_{tag}'] * 1e-3) / 1e12, 3)
+    out['gibbs_map_step_ms_f64'] = gibbs_map_step_ms(device, n)
     return out
+
+
+def gibbs_map_step_ms(device, n):
+    """One MAP training step of the Gibbs-kernel exact GP at N = n (BASELINE configs[1] on a synthetic lattice,
+    SURVEY 8d cfg2; the flow of experiments/spatial_exp.py:197-210 in float64): kernel build, log-normal prior
+    log-density of the lengthscale field (2 more N x N Cholesky factorisations), marginal likelihood, backward, Adam."""
+    import nsgp.gp as gpytorch
+    from models.gibbs_kernels import LogNormalPriorProcess
+    from models.nonstationary_models import DiagonalExactGP
+    side = int(round(n ** 0.5))
+    gx, gy = torch.meshgrid(torch.arange(side, dtype=torch.float64), torch.arange(n // side, dtype=torch.float64),
+                            indexing='ij')
+    x = torch.stack([gx.reshape(-1), gy.reshape(-1)], -1)
+    x = (x - x.mean(0)) / x.std(0)
+    y = torch.sin(3.0 * x[:, 0]) * torch.cos(2.0 * x[:, 1]) + 0.1 * torch.randn(x.shape[0], dtype=torch.float64,
+                                                                                    generator=torch.Generator().manual_seed(SEED))
+    prior = LogNormalPriorProcess(input_dim=2).double().to(device)
+    prior.covar_module.base_kernel.lengthscale = 1.3 * torch.ones_like(prior.covar_module.base_kernel.lengthscale)
+    prior.mean_module.constant = torch.nn.Parameter(math.log(0.3) * torch.ones_like(prior.mean_module.constant))
+    for p in prior.parameters():
+        p.requires_grad = False
+    lik = gpytorch.likelihoods.GaussianLikelihood().double()
+    model = DiagonalExactGP(x, y, lik, prior, num_dim=2).double().to(device)
+    model.likelihood.noise = 0.011
+    model.covar_module.outputscale = 0.644
+    for p in list(model.likelihood.noise_covar.parameters()) + [model.covar_module._parameters['raw_outputscale']]:
+        p.requires_grad = False
+    model.train()
+    lik.train()
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=0.01)
+    mll = gpytorch.mlls.ExactMarginalLogLikelihood(lik, model)
+    xd, yd = model.train_inputs[0], model.train_targets
+
+    def step():
+        opt.zero_grad()
+        loss = -mll(model(xd), yd)
+        loss.backward()
+        opt.step()
+    step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    return round(e0.elapsed_time(e1) / 3, 3)
 
 
 def main():
