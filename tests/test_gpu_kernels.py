@@ -529,3 +529,21 @@ def test_scalar_total_elbo_terms_match_autograd_of_the_vector_forms(ops, dt):
     for got, want in zip(dev, ref_in):
         w = want.grad if want is not L_r else torch.tril(want.grad)
         assert torch.allclose(got.grad.cpu().double(), w, **tol), got.shape
+
+
+@pytest.mark.parametrize('N', [4096, 5120, 4100])
+@pytest.mark.parametrize('ta,flag', [(False, 'A_LOWER'), (True, 'A_UPPER')])
+def test_gemm_narrow_tiles_for_single_round_triangular_launches(ops, N, ta, flag):
+    """M = K = 1024 with a triangular A operand and a grid that fits one round of the 512 slots takes the 128x64 tile
+    variant (three workgroups per CU): the hidden layer at one GPU (n = 4096), a rank's last layer at eight (n = 5120),
+    and a ragged width.  float32 against a float64 product of the same (masked) operands."""
+    g = _g(5 + N)
+    M = 1024
+    A = torch.randn(M, M, generator=g)
+    B = torch.randn(M, N, generator=g)
+    junk = torch.triu(torch.full((M, M), 3.0), 1)              # the ignored triangle holds garbage
+    Ain = torch.tril(A) + junk                                 # stored lower; with ta its transpose (upper) is the operand
+    ref = (torch.tril(A).double().t() if ta else torch.tril(A).double()) @ B.double()
+    out = ops.gemm(Ain.cuda(), B.cuda(), ta=ta, flags=getattr(ops, 'GEMM_' + flag))
+    err = float((out.cpu().double() - ref).abs().max()) / float(ref.abs().max())
+    assert err < 2e-6, err
