@@ -62,7 +62,7 @@ def run_split(dataset, random_state, args, device):
         frame = pd.DataFrame({'pred': (y_means.mean(0).cpu() * stdy + meany).numpy(),
                               'std': (y_var.mean(0).sqrt().cpu() * stdy).numpy(),
                               'lat': raw_x[:, 0], 'lon': raw_x[:, 1]})
-    return rmse_test, nlpd_test, float(loss), frame
+    return rmse_test, nlpd_test, float(loss.detach()), frame
 
 
 def main():

@@ -4,6 +4,7 @@ reference's experiments/deepgp_spatial_bench.py and experiments/spatial_exp.py. 
 uib_spatial.csv; the bands are sanity bands (the reference's results/*.csv come from unseeded 400-epoch runs:
 trained 2-layer DGP RMSE 0.5-0.6 in raw units), not parity assertions."""
 import importlib.util
+import math
 import os
 import sys
 import types
@@ -54,3 +55,15 @@ def test_gibbs_spatial_example_runs_exact_and_sparse(capsys, monkeypatch):
         line = [l for l in out.splitlines() if l.startswith('split 0:')][0]
         rm = float(line.split('RMSE test =')[1].split()[0])
         assert 0.1 < rm < 1.0, line
+
+
+def test_temporal_example_runs(capsys, monkeypatch):
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    mod = _load('temporal')
+    monkeypatch.setattr(sys, 'argv', ['temporal.py', '--iters', '40'])
+    mod.main()
+    out = capsys.readouterr().out
+    assert 'RMSE test' in out and 'NLPD test' in out
+    rm = float([l for l in out.splitlines() if l.startswith('RMSE test')][0].split('=')[1])
+    assert math.isfinite(rm) and rm > 0
