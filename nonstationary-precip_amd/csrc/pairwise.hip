@@ -331,8 +331,13 @@ int launch_fwd(const Op& op, int64_t batch, int64_t n1, int64_t n2, T diag_add, 
 // backward tile kernel (pass 1) and partial reduction (pass 2)
 // ------------------------------------------------------------------------------------------
 constexpr int BWD_TI = 64, BWD_TJ = 256;
+// Rows per backward workgroup: 64, or 16 when the 64-row grid would leave most of the 256 CUs idle (e.g. the float64
+// Kzz adjoint of the DSVI step: 1024 x 1024 x 2 GPs = 128 workgroups of 64 x 256 entries took 28 us, latency-bound).
+static inline int bwd_rows(int64_t batch, int64_t n1, int64_t n2) {
+    return batch * cdiv64(n1, BWD_TI) * cdiv64(n2, BWD_TJ) < 256 ? 16 : BWD_TI;
+}
 
-template <typename T, typename Op>
+template <typename T, typename Op, int TI>
 __global__ __launch_bounds__(256) void pairwise_bwd_kernel(Op op, int64_t n1, int64_t n2,
                                                            const T* __restrict__ G, int64_t ldg, int64_t sG,
                                                            T* __restrict__ P1, T* __restrict__ P2,
@@ -344,7 +349,7 @@ __global__ __launch_bounds__(256) void pairwise_bwd_kernel(Op op, int64_t n1, in
     const int64_t b = blockIdx.z;
     const int64_t tj = blockIdx.x, ti = blockIdx.y;
     const int64_t ntj = gridDim.x, nti = gridDim.y;
-    const int64_t j0 = tj * BWD_TJ, i0 = ti * BWD_TI;
+    const int64_t j0 = tj * BWD_TJ, i0 = ti * TI;
     const T* Gb = G + b * sG;
 
     typename Op::P cols[4];
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(256) void pairwise_bwd_kernel(Op op, int64_t n1, in
 #pragma unroll
     for (int k = 0; k < NG; ++k) ga[k] = T(0);
 
-    for (int r = w; r < BWD_TI; r += 4) {
+    for (int r = w; r < TI; r += 4) {
         const int64_t i = i0 + r;
         if (i >= n1) break;                         // wave-uniform
         const typename Op::P rp = op.row(b, i);
@@ -470,7 +475,7 @@ __global__ __launch_bounds__(256) void reduce_globals_kernel(const T* __restrict
 }
 
 template <typename Op> size_t bwd_ws_elems(int64_t batch, int64_t n1, int64_t n2) {
-    const int64_t ntj = cdiv64(n2, BWD_TJ), nti = cdiv64(n1, BWD_TI);
+    const int64_t ntj = cdiv64(n2, BWD_TJ), nti = cdiv64(n1, bwd_rows(batch, n1, n2));
     return (size_t)(batch * (ntj * n1 * Op::NR + nti * n2 * Op::NC + nti * ntj * Op::NG));
 }
 
@@ -479,14 +484,19 @@ int launch_bwd(const Op& op, int64_t batch, int64_t n1, int64_t n2, const T* G, 
                const OutDesc<T>& rows, const OutDesc<T>& cols, const OutDesc<T>& globs,
                void* ws, size_t ws_bytes, void* stream) {
     if (n1 == 0 || n2 == 0 || batch == 0) return 0;
-    const int64_t ntj = cdiv64(n2, BWD_TJ), nti = cdiv64(n1, BWD_TI);
+    const int ti_rows = bwd_rows(batch, n1, n2);
+    const int64_t ntj = cdiv64(n2, BWD_TJ), nti = cdiv64(n1, ti_rows);
     if (ws_bytes < bwd_ws_elems<Op>(batch, n1, n2) * sizeof(T) || !ws) return -100;
     T* P1 = (T*)ws;
     T* P2 = P1 + batch * ntj * n1 * Op::NR;
     T* PG = P2 + batch * nti * n2 * Op::NC;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL((pairwise_bwd_kernel<T, Op>), dim3((unsigned)ntj, (unsigned)nti, (unsigned)batch), dim3(256),
-                       0, st, op, n1, n2, G, ldg, sG, P1, P2, PG);
+    if (ti_rows == 16)
+        hipLaunchKernelGGL((pairwise_bwd_kernel<T, Op, 16>), dim3((unsigned)ntj, (unsigned)nti, (unsigned)batch),
+                           dim3(256), 0, st, op, n1, n2, G, ldg, sG, P1, P2, PG);
+    else
+        hipLaunchKernelGGL((pairwise_bwd_kernel<T, Op, BWD_TI>), dim3((unsigned)ntj, (unsigned)nti, (unsigned)batch),
+                           dim3(256), 0, st, op, n1, n2, G, ldg, sG, P1, P2, PG);
     hipLaunchKernelGGL((reduce_items_kernel<T>), dim3((unsigned)cdiv64(n1 * Op::NR, 32), 1, (unsigned)batch),
                        dim3(256), 0, st, (const T*)P1, ntj, n1, rows);
     hipLaunchKernelGGL((reduce_items_kernel<T>), dim3((unsigned)cdiv64(n2 * Op::NC, 32), 1, (unsigned)batch),
