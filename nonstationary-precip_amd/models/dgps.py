@@ -74,15 +74,19 @@ class DeepGP(_DeepGPBase):
         return self.last_layer(rep)
 
     def predict(self, test_loader):
-        """(last batch's predictive, means (S,N), variances (S,N), per-point log marginals (S,N))."""
-        mus, variances, lls = [], [], []
+        """Returns (predictive of the LAST batch, means (S,N), variances (S,N), per-point log marginals (S,N)):
+        the tuple of the reference's DeepGP.predict (:100-111).  Each batch is propagated twice, once for the
+        noisy predictive and once for the log marginal of its targets, exactly like the reference."""
+        parts = {'mean': [], 'variance': [], 'll': []}
+        last_predictive = None
         with torch.no_grad():
-            for x_batch, y_batch in test_loader:
-                preds = self.likelihood(self(x_batch))
-                mus.append(preds.mean)
-                variances.append(preds.variance)
-                lls.append(self.likelihood.log_marginal(y_batch, self(x_batch)))
-        return preds, torch.cat(mus, dim=-1), torch.cat(variances, dim=-1), torch.cat(lls, dim=-1)
+            for xb, yb in test_loader:
+                last_predictive = self.likelihood(self(xb))
+                parts['mean'].append(last_predictive.mean)
+                parts['variance'].append(last_predictive.variance)
+                parts['ll'].append(self.likelihood.log_marginal(yb, self(xb)))
+        joined = {k: torch.cat(v, dim=-1) for k, v in parts.items()}
+        return last_predictive, joined['mean'], joined['variance'], joined['ll']
 
 
 class ExactGPModel(ExactGP):

@@ -1,18 +1,33 @@
-"""Constants with the reference's names (utils/config.py:10-20)."""
-from pathlib import Path
+"""Run-wide constants under the names the reference's scripts import from `utils.config`
+(`from utils.config import BASE_SEED, EPSILON, DATASET_DIR`, experiments/deepgp_spatial_bench.py:18 and
+experiments/spatial_exp.py:28): seeds and tolerances, library versions, device census, data / results locations.
+The bundled CSVs live under tests/golden/data/ in this repository (they double as test fixtures)."""
+import pathlib
 
 import torch
 
-import nsgp.gp as gpytorch
+import nsgp.gp as _gp
 
-TORCH_VERSION = torch.__version__
-GPYTORCH_VERSION = gpytorch.__version__
+__all__ = ['BASE_SEED', 'EPSILON', 'TORCH_VERSION', 'GPYTORCH_VERSION', 'AVAILABLE_GPU', 'GPU_ACTIVE', 'BASE_PATH',
+           'RESULTS_DIR', 'DATASET_DIR']
 
-AVAILABLE_GPU = torch.cuda.device_count()
-GPU_ACTIVE = bool(AVAILABLE_GPU)
-EPSILON = 1e-5
-BASE_SEED = 173
+# reproducibility / numerics
+BASE_SEED: int = 173          # split i of an experiment uses BASE_SEED + i
+EPSILON: float = 1e-5         # passed to gpytorch.settings.cholesky_jitter by the scripts
 
-BASE_PATH = Path(__file__).resolve().parent.parent.parent
-RESULTS_DIR = BASE_PATH / 'results'
-DATASET_DIR = BASE_PATH / 'tests' / 'golden' / 'data'      # the bundled uib_* / khyber_* CSVs
+
+def _repo_root() -> pathlib.Path:
+    here = pathlib.Path(__file__).resolve()
+    return here.parents[2]    # <repo>/nonstationary-precip_amd/utils/config.py -> <repo>
+
+
+# locations
+BASE_PATH = _repo_root()
+DATASET_DIR = BASE_PATH.joinpath('tests', 'golden', 'data')      # uib_spatial.csv, uib_spatio_temporal.csv, khyber_time_series.csv
+RESULTS_DIR = BASE_PATH.joinpath('results')
+
+# environment census
+AVAILABLE_GPU: int = torch.cuda.device_count()
+GPU_ACTIVE: bool = AVAILABLE_GPU > 0
+TORCH_VERSION: str = torch.__version__
+GPYTORCH_VERSION: str = _gp.__version__      # the nsgp.gp namespace stands in for gpytorch
