@@ -4,11 +4,11 @@ inducing size?  M = 1024 inducing points, 2-layer DeepGP; the float64 CPU oracle
 reference, the GPU model runs with the float64 and with the float32 adjoint on the same parameters and noise.
 Prints the max-norm relative error of every parameter gradient for both variants.
 
-    python tools/chol_adjoint_precision.py [B] [S]        (defaults 512, 2: keeps the CPU oracle at a few seconds)
+    python tests/manual/chol_adjoint_precision.py [B] [S]        (defaults 512, 2: keeps the CPU oracle at a few seconds)
 """
 import os
 import sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'nonstationary-precip_amd'))
 import torch  # noqa: E402
