@@ -8,6 +8,11 @@
 // operands live in registers for the whole tile and the row operands are computed once per tile and
 // broadcast-read from LDS.
 // Algorithmic bytes per build: s*(n1*n2 + 2*D*(n1+n2)).
+// Measured at N = 16384 (tools/probes/): a torch fill_ writes 6.85 TB/s; this kernel with the arithmetic stubbed out
+// reaches 5.8 TB/s (float32) / 6.2 TB/s (float64), and the real Gibbs build 5.7 / 5.0 TB/s -- float32 sits on the
+// skeleton's ceiling, float64 still pays ~43 VALU instructions per entry (custom exp and rsqrt in common.h).
+// Tried without gain: v_pk_* arithmetic on column pairs, non-temporal stores, 16 x (256*CPT) tiles with the four waves
+// side by side (-12 %), an XCD-contiguous tile order.
 //
 // Backward: one pass over G (dLoss/dK).  A workgroup owns a 64 x 256 tile: wave w walks rows
 // w, w+4, ..; a lane covers 4 columns 64 apart (coalesced G reads).  Row-side gradients are
@@ -58,9 +63,10 @@ template <typename T, int D> struct GibbsOp {
     __device__ __forceinline__ P col(int64_t, int64_t j) const { return point(x2, l2, n2, j); }
     // unscaled kernel value
     __device__ __forceinline__ T base(const P& r, const P& c) const {
-        T S = T(1), num = T(0);
+        T S = r.q[0] + c.q[0];
+        T num = (r.x[0] - c.x[0]) * (r.x[0] - c.x[0]);
 #pragma unroll
-        for (int d = 0; d < DM; ++d) {
+        for (int d = 1; d < DM; ++d) {
             if (D || d < Drt) {
                 const T s = r.q[d] + c.q[d];
                 const T df = r.x[d] - c.x[d];
@@ -72,6 +78,9 @@ template <typename T, int D> struct GibbsOp {
         return r.h * c.h * rs * t_fexp(-num * rs * rs);
     }
     __device__ __forceinline__ T eval(int64_t, const P& r, const P& c) const { return os() * base(r, c); }
+    // forward-build variants: the output scale is folded into the column operand once per thread
+    __device__ __forceinline__ P fcol(int64_t b, int64_t j) const { P p = col(b, j); p.h *= os(); return p; }
+    __device__ __forceinline__ T feval(int64_t, const P& r, const P& c) const { return base(r, c); }
     // accumulate g * d k / d(param) into row / col / global accumulators
     __device__ __forceinline__ void grad(int64_t, const P& r, const P& c, T g, T* ra, T* ca, T* ga) const {
         const T kb = base(r, c);
@@ -126,6 +135,8 @@ template <typename T, int D> struct RbfOp {
         return t_fexp(T(-0.5) * ex);
     }
     __device__ __forceinline__ T eval(int64_t b, const P& r, const P& c) const { return os[b] * base(r, c); }
+    __device__ __forceinline__ P fcol(int64_t b, int64_t j) const { return col(b, j); }
+    __device__ __forceinline__ T feval(int64_t b, const P& r, const P& c) const { return eval(b, r, c); }
     // row/col accumulators are in units of d/d(x/ls) ("scaled x"); pass 2 divides by ls.
     __device__ __forceinline__ void grad(int64_t b, const P& r, const P& c, T g, T* ra, T* ca, T* ga) const {
         const T kb = base(r, c);
@@ -187,6 +198,8 @@ template <typename T, int D> struct RbfPeriodicOp {
         const T k = base(b, r, c, rr, sn, cs);
         return os ? os[b] * k : k;
     }
+    __device__ __forceinline__ P fcol(int64_t b, int64_t j) const { return col(b, j); }
+    __device__ __forceinline__ T feval(int64_t b, const P& r, const P& c) const { return eval(b, r, c); }
     __device__ __forceinline__ void grad(int64_t b, const P& r, const P& c, T g, T* ra, T* ca, T* ga) const {
         T rr, sn, cs;
         const T kb = base(b, r, c, rr, sn, cs);
@@ -230,6 +243,8 @@ template <typename T> struct PsOp {
     }
     __device__ __forceinline__ P row(int64_t, int64_t i) const { return load(x1, s1, i); }
     __device__ __forceinline__ P col(int64_t, int64_t j) const { return load(x2, s2, j); }
+    __device__ __forceinline__ P fcol(int64_t b, int64_t j) const { return col(b, j); }
+    __device__ __forceinline__ T feval(int64_t b, const P& r, const P& c) const { return eval(b, r, c); }
     __device__ __forceinline__ T eval(int64_t, const P& r, const P& c) const {
         const T a0 = T(0.5) * (r.s[0] + c.s[0]), a1 = T(0.5) * (r.s[1] + c.s[1]);
         const T a2 = T(0.5) * (r.s[2] + c.s[2]), a3 = T(0.5) * (r.s[3] + c.s[3]);
@@ -282,7 +297,8 @@ __global__ __launch_bounds__(256) void pairwise_fwd_kernel(Op op, int64_t n1, in
     __shared__ typename Op::P rows_s[FWD_TI];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t b = blockIdx.z;
-    const int64_t j0 = ((int64_t)blockIdx.x * 64 + lane) * CPT;
+    const int64_t jb = (int64_t)blockIdx.x * 64 * CPT;
+    const int64_t j0 = jb + (int64_t)lane * CPT;
     const int64_t i0 = (int64_t)blockIdx.y * FWD_TI;
     // row operands of the tile: computed once (one thread per row), then broadcast-read from LDS
     if (threadIdx.x < FWD_TI && i0 + threadIdx.x < n1) rows_s[threadIdx.x] = op.row(b, i0 + threadIdx.x);
@@ -291,24 +307,35 @@ __global__ __launch_bounds__(256) void pairwise_fwd_kernel(Op op, int64_t n1, in
     const T diag_add = diag_add_p ? diag_add_p[0] : diag_add_v;
     typename Op::P cols[CPT];
 #pragma unroll
-    for (int c = 0; c < CPT; ++c) cols[c] = op.col(b, j0 + c < n2 ? j0 + c : n2 - 1);
+    for (int c = 0; c < CPT; ++c) cols[c] = op.fcol(b, j0 + c < n2 ? j0 + c : n2 - 1);
     T* Kb = K + b * sK;
     const bool full = vec_ok && (j0 + CPT <= n2);
-    for (int r = w; r < FWD_TI; r += 4) {
-        const int64_t i = i0 + r;
-        if (i >= n1) break;
+    const int rmax = (int)(n1 - i0 < FWD_TI ? n1 - i0 : FWD_TI);
+    // only tiles that cross the diagonal test for it (block-uniform)
+    const bool on_diag = i0 < jb + 64 * CPT && jb < i0 + FWD_TI;
+    auto entry = [&](int r, T (&v)[CPT]) {
         const typename Op::P rp = rows_s[r];
-        T v[CPT];
 #pragma unroll
-        for (int c = 0; c < CPT; ++c) {
-            v[c] = op.eval(b, rp, cols[c]);
-            if (i == j0 + c) v[c] += diag_add;
+        for (int c = 0; c < CPT; ++c) v[c] = op.feval(b, rp, cols[c]);
+        if (on_diag) {
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) if (i0 + r == j0 + c) v[c] += diag_add;
         }
-        T* dst = Kb + i * ldk + j0;
-        if (full) {
+    };
+    if (full) {
+#pragma unroll 2
+        for (int r = w; r < rmax; r += 4) {
+            T v[CPT];
+            entry(r, v);
+            T* dst = Kb + (i0 + r) * ldk + j0;
             if constexpr (CPT == 4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
             else *reinterpret_cast<double2*>(dst) = make_double2(v[0], v[1]);
-        } else {
+        }
+    } else {
+        for (int r = w; r < rmax; r += 4) {
+            T v[CPT];
+            entry(r, v);
+            T* dst = Kb + (i0 + r) * ldk + j0;
 #pragma unroll
             for (int c = 0; c < CPT; ++c) if (j0 + c < n2) dst[c] = v[c];
         }
