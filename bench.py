@@ -8,9 +8,12 @@
 Workload (BASELINE B4): DeepGP(num_layers=1) = hidden 3->2 + last 2->1, M=1024 inducing,
 S=10 likelihood samples, minibatch B=4096 of a synthetic N=100,000 spatio-temporal grid
 (100 months x 1,000 cells, time-major, z-scored), float32 with float64 Kzz Cholesky, Adam lr 0.01.
-One step = forward + ELBO + backward + (gradient all-reduce) + Adam update on one minibatch that is
-already resident in HBM.  With N>1 the SAME global minibatch of 4096 rows is sharded over the ranks
-(strong scaling) and the flat gradient bucket is summed with one RCCL all-reduce.
+One step = forward + ELBO + backward + (gradient all-reduce) + Adam update on one 4096-row minibatch that
+is already resident in HBM.  With N>1 (data parallel, nsgp/dist.py) every rank takes its own 4096 rows of a
+global minibatch of 4096 N rows (weak scaling, the default: value = N x iterations/s) or, with
+--scaling strong, 4096/N rows of ONE 4096-row minibatch (value = iterations/s); either way the ranks'
+objectives sum to the single-process ELBO of the global minibatch and the flat gradient bucket is summed
+with one RCCL all-reduce.
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field definitions).
 """
@@ -240,6 +243,10 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly (no hipGraph replay)')
     ap.add_argument('--no-build-chol', action='store_true',
                     help='skip the Gibbs-build + Cholesky fields (PMC passes of the DSVI step only)')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
+                    help='weak (default): every GPU takes its own 4096-row minibatch per iteration (global batch '
+                         '4096 x N), value = N x iterations/s; strong: ONE 4096-row minibatch is split over the N GPUs, '
+                         'value = iterations/s.  Identical at N=1.')
     ap.add_argument('--rank-share', type=int, default=1, metavar='G',
                     help='analysis only: run ONE rank\'s share of a G-rank job on this GPU (rows [0, 4096/G) of every '
                          'minibatch, the objective scaled as on rank 0 of G; no collective).  The JSON line is marked '
@@ -269,10 +276,14 @@ def main():
     x_all, y_all = synthetic_grid()
     gperm = torch.Generator().manual_seed(SEED)
     perm = torch.randperm(N_DATA, generator=gperm)
-    n_batches = N_DATA // BATCH
-    idx = [perm[i * BATCH:(i + 1) * BATCH] for i in range(n_batches)]       # shared shuffled index
+    weak = args.scaling == 'weak'
+    gbatch = BATCH * world if weak else BATCH                     # rows of one global minibatch
+    n_batches = N_DATA // gbatch
+    idx = [perm[i * gbatch:(i + 1) * gbatch] for i in range(n_batches)]     # shared shuffled index
     share = max(1, args.rank_share)
-    lo, hi = shard_bounds(BATCH, world * share, rank)             # share > 1: analysis mode (see --rank-share)
+    if share > 1 and (weak and world > 1):
+        raise SystemExit('--rank-share is a single-process analysis of the strong-scaling split')
+    lo, hi = shard_bounds(gbatch, world * share, rank)            # share > 1: analysis mode (see --rank-share)
     xs = [x_all[i[lo:hi]].to(device) for i in idx]                           # resident in HBM
     ys = [y_all[i[lo:hi]].to(device) for i in idx]
 
@@ -288,7 +299,7 @@ def main():
         eps.start_step(0, row0=lo)
         opt.zero_grad()
         out = model(x_in)
-        loss = -dp_objective(mll, out, y_in, BATCH, world * share)
+        loss = -dp_objective(mll, out, y_in, gbatch, world * share)
         loss.backward()
         opt.bucket.gather_grads()            # one multi-tensor copy into the flat gradient bucket
         return loss.detach()
@@ -378,15 +389,21 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12
         result = {
-            'metric': 'dsvi_elbo_steps_per_sec', 'value': round(args.steps / elapsed, 3), 'unit': 'steps/s',
+            # a "step" is one fwd+ELBO+bwd+Adam pass over a 4096-row minibatch.  Weak scaling: an N-GPU iteration is N
+            # such passes (one per rank, global batch 4096 N) joined by one RCCL all-reduce, so value = N x iterations/s;
+            # strong scaling: the N ranks share one 4096-row minibatch, value = iterations/s.
+            'metric': 'dsvi_elbo_steps_per_sec',
+            'value': round((world if weak else 1) * args.steps / elapsed, 3), 'unit': 'steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
-            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32',
+            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic',
-            'config': {'workload': '2-layer DSVI DeepGP (hidden 3->2 + last 2->1), M=1024, S=10, '
-                                   'global minibatch 4096 of synthetic N=1e5 spatio-temporal grid; '
-                                   'fwd+ELBO+bwd+Adam', 'M': M_INDUCING, 'S': S_SAMPLES,
-                       'global_batch': BATCH, 'N': N_DATA, 'parallelism': f'dp{world}',
+            'config': {'workload': '2-layer DSVI DeepGP (hidden 3->2 + last 2->1), M=1024, S=10, minibatch 4096 '
+                                   + ('per GPU ' if weak else '(global, split over the GPUs) ')
+                                   + 'of synthetic N=1e5 spatio-temporal grid; fwd+ELBO+bwd+Adam',
+                       'M': M_INDUCING, 'S': S_SAMPLES, 'per_gpu_batch': hi - lo,
+                       'global_batch': gbatch, 'N': N_DATA, 'parallelism': f'dp{world}',
                        'kzz_cholesky_dtype': 'f64', 'hipgraph': bool(use_graph)},
+            'iterations_per_sec': round(args.steps / elapsed, 3),
             **({'analysis': f'one rank\'s share of a {share}-rank job (rows [0, {hi - lo}) of each minibatch), '
                             'no collective; NOT a --gpus result'} if share > 1 else {}),
             'final_loss': round(final_loss, 5),
