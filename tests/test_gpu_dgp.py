@@ -129,6 +129,50 @@ def test_dsvi_elbo_and_gradients_match_oracle(num_layers, D, M, B, S, chol_bwd_f
     print('max grad rel err', chol_bwd_f64, max(errs.values()), max(errs, key=errs.get))
 
 
+def test_cfg5_three_layer_m2048_three_output_dims_matches_oracle():
+    """BASELINE configs[4] shape at a reduced minibatch: DeepGP(num_layers=2) = the tied hidden layer applied twice
+    + the last layer, M=2048 inducing points, 3-D inputs, so `num_output_dims` has to be 3 (the tied layer feeds
+    itself).  Exercises the two-level potrf / trtri (n >= 2048) and three hidden GPs inside the DSVI step.
+    float32 pipeline vs float64 oracle; 2048 random inducing points in 3-D make Kzz far worse conditioned than the
+    small cases above; tolerances are stated at the asserts."""
+    _need_gpu()
+    import models.dgps as m
+    from oracle import svgp
+    from nsgp.gp.mlls import DeepApproximateMLL, VariationalELBO
+    old = m.num_output_dims
+    m.num_output_dims = 3
+    try:
+        model, settings = _build(2, 3, 2048, 2048)
+    finally:
+        m.num_output_dims = old
+    assert model.layers[0] is model.layers[1] and model.layers[0].output_dims == 3
+    B, S, N = 192, 3, 1_000_000
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, 3, generator=g)
+    y = torch.randn(B, generator=g)
+    eps = [torch.randn(S, B, 3, generator=g) for _ in range(2)]
+    mll = DeepApproximateMLL(VariationalELBO(model.likelihood, model, N))
+    model.train()
+    with settings.num_likelihood_samples(S), settings.eps_provider(_FixedEps(eps)):
+        out = model(x.cuda())
+        elbo = mll(out, y.cuda())
+        assert out.mean.shape == (S, B)
+        elbo.backward()
+    hidden, last, noise, leaves = _oracle_layers(model)
+    ref = svgp.dsvi_elbo(x.double(), y.double(), hidden, last, 2, [e.double() for e in eps], S, noise, N)
+    ref.backward()
+    rel = abs(float(elbo.detach()) - float(ref.detach())) / abs(float(ref.detach()))
+    errs = {}
+    for name, p in _model_params(model).items():
+        got, want = p.grad.detach().cpu().double(), leaves[name].grad
+        if name.endswith('Lq'):
+            want = torch.tril(want)
+        errs[name] = float((got - want).abs().max()) / (float(want.abs().max()) + 1e-12)
+    print('cfg5 shape: ELBO rel err %.2e, grad rel errs' % rel, {k: '%.1e' % v for k, v in errs.items()})
+    assert rel < 2e-5                                      # ELBO: 2e-5 relative (measured 8e-7)
+    assert max(errs.values()) < 5e-3, errs                 # per-parameter max-norm relative gradient error (measured 9e-4)
+
+
 def test_predict_matches_oracle_and_full_covariance_is_consistent():
     _need_gpu()
     from oracle import svgp
