@@ -245,6 +245,32 @@ int nsgp_svgp_lqbar_f32(const float* A, const float* C, const float* gvar, int64
                         float* Lqbar, void* ws, size_t ws_bytes, void* stream);
 int nsgp_svgp_lqbar_f64(const double* A, const double* C, const double* gvar, int64_t batch, int64_t M, int64_t n,
                         double* Lqbar, void* ws, size_t ws_bytes, void* stream);
+/* The same two steps with the layer's affine prior mean and the cheap column reductions folded in, so that the mean
+ * module of models/dgps.py:40-43 (gpytorch ConstantMean / LinearMean), the `+ 1e-4` of the predictive variance and the
+ * output-scale gradient cost no launches of their own:
+ *   colstats_finalize_affine: mean = sum_t part_dot + sum_d x[b,j,d] w[b,d] + c[b];
+ *                             var  = (base + base_add) + sum_t (part_sq_c - part_sq_a).
+ *       x:(.., n, D) row-major, w:(.., D), c:(..,) with BATCH strides that may be 0 (shared by the batch);
+ *       w and/or c may be NULL (no linear / constant part).
+ *   rowdot_affine: out[b,k] = sum_j A[b,k,j] g[b,j];  out_gv[b] = sum_j gv[b,j] (gv may be NULL);
+ *                  out_1 = sum_j g[b,j];  out_x[d] = sum_j x[b,j,d] g[b,j]  -- per batch ((batch,), (batch,D)) or, with
+ *                  shared != 0, summed over the batch ((1,), (D,)); out_1 / out_x may be NULL. */
+int nsgp_svgp_colstats_finalize_affine_f32(const float* part_dot, const float* part_sq_a, const float* part_sq_c,
+                                           const float* base, float base_add, int64_t batch, int64_t tiles, int64_t n,
+                                           const float* x, int64_t x_batch_stride, int64_t D, const float* w,
+                                           int64_t w_batch_stride, const float* c, int64_t c_batch_stride, float* mean,
+                                           float* var, void* stream);
+int nsgp_svgp_colstats_finalize_affine_f64(const double* part_dot, const double* part_sq_a, const double* part_sq_c,
+                                           const double* base, double base_add, int64_t batch, int64_t tiles,
+                                           int64_t n, const double* x, int64_t x_batch_stride, int64_t D,
+                                           const double* w, int64_t w_batch_stride, const double* c,
+                                           int64_t c_batch_stride, double* mean, double* var, void* stream);
+int nsgp_rowdot_affine_f32(const float* A, const float* g, const float* gv, const float* x, int64_t x_batch_stride,
+                           int64_t D, int shared, int64_t batch, int64_t M, int64_t n, float* out, float* out_gv,
+                           float* out_x, float* out_1, void* stream);
+int nsgp_rowdot_affine_f64(const double* A, const double* g, const double* gv, const double* x, int64_t x_batch_stride,
+                           int64_t D, int shared, int64_t batch, int64_t M, int64_t n, double* out, double* out_gv,
+                           double* out_x, double* out_1, void* stream);
 int nsgp_rowdot_f32(const float* A, const float* g, int64_t batch, int64_t M, int64_t n, float* out, void* stream);
 int nsgp_rowdot_f64(const double* A, const double* g, int64_t batch, int64_t M, int64_t n, double* out,
                     void* stream);

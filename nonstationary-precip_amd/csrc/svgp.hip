@@ -42,10 +42,15 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ A, 
 }
 
 // ---- colstats from the GEMM epilogues' per-tile-row partial sums ----------------------------------
+// Optional affine prior mean added on the way out (gpytorch ConstantMean / LinearMean of models/dgps.py:40-43):
+//   mean[b,j] += sum_d x[b,j,d] w[b,d] + c[b]   (x / w / c batch strides may be 0 = shared; w or c may be null).
 template <typename T>
 __global__ void colstats_finalize_kernel(const T* __restrict__ pdot, const T* __restrict__ psqA,
-                                         const T* __restrict__ psqC, const T* __restrict__ base, int64_t batch,
-                                         int64_t tiles, int64_t n, T* __restrict__ mean, T* __restrict__ var) {
+                                         const T* __restrict__ psqC, const T* __restrict__ base, T base_add,
+                                         int64_t batch, int64_t tiles, int64_t n, const T* __restrict__ x,
+                                         int64_t sxb, int D, const T* __restrict__ w, int64_t swb,
+                                         const T* __restrict__ c, int64_t scb, T* __restrict__ mean,
+                                         T* __restrict__ var) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= batch * n) return;
     const int64_t b = idx / n, j = idx % n;
@@ -54,8 +59,16 @@ __global__ void colstats_finalize_kernel(const T* __restrict__ pdot, const T* __
         const int64_t o = (b * tiles + t) * n + j;
         sm += pdot[o]; sa += psqA[o]; sc += psqC[o];
     }
+    if (w) {
+        const T* xr = x + b * sxb + j * D;
+        const T* wr = w + b * swb;
+        T mu = T(0);
+        for (int d = 0; d < D; ++d) mu += xr[d] * wr[d];
+        sm += mu;
+    }
+    if (c) sm += c[b * scb];
     mean[idx] = sm;
-    var[idx] = base[b] + (sc - sa);
+    var[idx] = (base[b] + base_add) + (sc - sa);
 }
 
 // ---- out[b][i] = sum_j A[b][i][j] * g[b][j]  (one workgroup per row; the m-gradient  A gmean) ------
@@ -86,6 +99,73 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const T* __restrict__ A, co
     }
     acc = block_sum_256(acc, lds);
     if (threadIdx.x == 0) out[b * M + i] = acc;
+}
+
+// ---- rowdot plus the reductions over the same columns that the layer's adjoint needs anyway:
+//   rows i < M        : out[b,i]  = sum_j A[b,i,j] g[b,j]                      (mbar = A gmean)
+//   row  M            : out_gv[b] = sum_j gv[b,j]                              (d/d outputscale through `base`)
+//   row  M+1          : out_1     = sum_j g[b,j]                               (constant mean / bias gradient)
+//   rows M+2 .. M+1+D : out_x[d]  = sum_j x[b,j,d] g[b,j]                      (linear-mean weight gradient)
+// out_1 / out_x are per batch, or summed over the batch when the mean parameters are shared (`shared`).
+template <typename T>
+__global__ __launch_bounds__(256) void rowdot_affine_kernel(const T* __restrict__ A, const T* __restrict__ g,
+                                                            const T* __restrict__ gv, const T* __restrict__ x,
+                                                            int64_t sxb, int D, int shared, int64_t batch, int64_t M,
+                                                            int64_t n, T* __restrict__ out, T* __restrict__ out_gv,
+                                                            T* __restrict__ out_x, T* __restrict__ out_1) {
+    __shared__ T lds[4];
+    const int64_t b = blockIdx.y, i = blockIdx.x;
+    T acc = T(0);
+    if (i < M) {
+        const T* row = A + (b * M + i) * n;
+        const T* gb = g + b * n;
+        constexpr int V = 16 / sizeof(T);
+        const bool vec = (n % V == 0) && ((uintptr_t)row % 16 == 0) && ((uintptr_t)gb % 16 == 0);
+        if (vec) {
+            for (int64_t j = (int64_t)threadIdx.x * V; j < n; j += 256 * V) {
+                if constexpr (sizeof(T) == 4) {
+                    const float4 a = *reinterpret_cast<const float4*>(row + j);
+                    const float4 q = *reinterpret_cast<const float4*>(gb + j);
+                    acc += a.x * q.x + a.y * q.y + a.z * q.z + a.w * q.w;
+                } else {
+                    const double2 a = *reinterpret_cast<const double2*>(row + j);
+                    const double2 q = *reinterpret_cast<const double2*>(gb + j);
+                    acc += a.x * q.x + a.y * q.y;
+                }
+            }
+        } else {
+            for (int64_t j = threadIdx.x; j < n; j += 256) acc += row[j] * gb[j];
+        }
+        acc = block_sum_256(acc, lds);
+        if (threadIdx.x == 0) out[b * M + i] = acc;
+        return;
+    }
+    const int e = (int)(i - M);
+    if (e == 0) {
+        if (!gv) return;
+        const T* q = gv + b * n;
+        for (int64_t j = threadIdx.x; j < n; j += 256) acc += q[j];
+        acc = block_sum_256(acc, lds);
+        if (threadIdx.x == 0) out_gv[b] = acc;
+        return;
+    }
+    if (e == 1 ? !out_1 : !out_x) return;
+    if (shared && b != 0) return;
+    const int64_t b1 = shared ? batch : b + 1;
+    for (int64_t bb = b; bb < b1; ++bb) {
+        const T* gb = g + bb * n;
+        if (e == 1) {
+            for (int64_t j = threadIdx.x; j < n; j += 256) acc += gb[j];
+        } else {
+            const T* xc = x + bb * sxb + (e - 2);
+            for (int64_t j = threadIdx.x; j < n; j += 256) acc += xc[j * D] * gb[j];
+        }
+    }
+    acc = block_sum_256(acc, lds);
+    if (threadIdx.x == 0) {
+        if (e == 1) out_1[shared ? 0 : b] = acc;
+        else out_x[(shared ? 0 : b) * D + (e - 2)] = acc;
+    }
 }
 
 // ---- colstats backward: one block per (row k, batch b) ------------------------------------------
@@ -364,6 +444,36 @@ int kl_bwd_impl(const T* m, const T* Lq, int64_t batch, int64_t M, T gout, T* gm
 
 }  // namespace
 
+template <typename T>
+static int finalize_affine_impl(const T* part_dot, const T* part_sq_a, const T* part_sq_c, const T* base, T base_add,
+                                int64_t batch, int64_t tiles, int64_t n, const T* x, int64_t sxb, int64_t D, const T* w,
+                                int64_t swb, const T* c, int64_t scb, T* mean, T* var, void* stream) {
+    if (!part_dot) return -1; if (!part_sq_a) return -2; if (!part_sq_c) return -3; if (!base) return -4;
+    if (batch < 0) return -6; if (tiles < 0) return -7; if (n < 0) return -8;
+    if (w && !x) return -9; if (sxb < 0) return -10; if (D < 0 || D > NSGP_MAX_DIM || (w && D == 0)) return -11;
+    if (swb < 0) return -13; if (scb < 0) return -15; if (!mean) return -16; if (!var) return -17;
+    if (batch * n == 0) return 0;
+    hipLaunchKernelGGL((colstats_finalize_kernel<T>), dim3((unsigned)cdiv64(batch * n, 256)), dim3(256), 0,
+                       (hipStream_t)stream, part_dot, part_sq_a, part_sq_c, base, base_add, batch, tiles, n, x, sxb,
+                       (int)D, w, swb, c, scb, mean, var);
+    return nsgp_launch_status();
+}
+
+template <typename T>
+static int rowdot_affine_impl(const T* A, const T* g, const T* gv, const T* x, int64_t sxb, int64_t D, int shared,
+                              int64_t batch, int64_t M, int64_t n, T* out, T* out_gv, T* out_x, T* out_1,
+                              void* stream) {
+    if (!A) return -1; if (!g) return -2; if (sxb < 0) return -5; if (D < 0 || D > NSGP_MAX_DIM) return -6;
+    if (batch < 0) return -8; if (M < 0) return -9; if (n < 0) return -10; if (!out) return -11;
+    if (gv && !out_gv) return -12; if (out_x && (!x || D == 0)) return -13;
+    if (batch == 0) return 0;
+    const int64_t rows = M + 2 + (out_x ? D : 0);
+    if (rows > 2147483647LL || batch > 65535) return -9;
+    hipLaunchKernelGGL((rowdot_affine_kernel<T>), dim3((unsigned)rows, (unsigned)batch), dim3(256), 0,
+                       (hipStream_t)stream, A, g, gv, x, sxb, (int)D, shared, batch, M, n, out, out_gv, out_x, out_1);
+    return nsgp_launch_status();
+}
+
 extern "C" {
 
 size_t nsgp_reduce_workspace(int64_t n_elems, int elem_size) {
@@ -448,7 +558,9 @@ int nsgp_svgp_colstats_finalize_f32(const float* part_dot, const float* part_sq_
     if (batch < 0) return -5; if (tiles < 0) return -6; if (n < 0) return -7; if (!mean) return -8; if (!var) return -9;
     if (batch * n == 0) return 0;
     hipLaunchKernelGGL((colstats_finalize_kernel<float>), dim3((unsigned)cdiv64(batch * n, 256)), dim3(256), 0,
-                       (hipStream_t)stream, part_dot, part_sq_a, part_sq_c, base, batch, tiles, n, mean, var);
+                       (hipStream_t)stream, part_dot, part_sq_a, part_sq_c, base, (float)0, batch, tiles, n,
+                       (const float*)nullptr, (int64_t)0, 0, (const float*)nullptr, (int64_t)0, (const float*)nullptr,
+                       (int64_t)0, mean, var);
     return nsgp_launch_status();
 }
 int nsgp_svgp_colstats_finalize_f64(const double* part_dot, const double* part_sq_a, const double* part_sq_c,
@@ -458,8 +570,38 @@ int nsgp_svgp_colstats_finalize_f64(const double* part_dot, const double* part_s
     if (batch < 0) return -5; if (tiles < 0) return -6; if (n < 0) return -7; if (!mean) return -8; if (!var) return -9;
     if (batch * n == 0) return 0;
     hipLaunchKernelGGL((colstats_finalize_kernel<double>), dim3((unsigned)cdiv64(batch * n, 256)), dim3(256), 0,
-                       (hipStream_t)stream, part_dot, part_sq_a, part_sq_c, base, batch, tiles, n, mean, var);
+                       (hipStream_t)stream, part_dot, part_sq_a, part_sq_c, base, (double)0, batch, tiles, n,
+                       (const double*)nullptr, (int64_t)0, 0, (const double*)nullptr, (int64_t)0, (const double*)nullptr,
+                       (int64_t)0, mean, var);
     return nsgp_launch_status();
+}
+int nsgp_svgp_colstats_finalize_affine_f32(const float* part_dot, const float* part_sq_a, const float* part_sq_c,
+                                           const float* base, float base_add, int64_t batch, int64_t tiles, int64_t n,
+                                           const float* x, int64_t x_batch_stride, int64_t D, const float* w,
+                                           int64_t w_batch_stride, const float* c, int64_t c_batch_stride, float* mean,
+                                           float* var, void* stream) {
+    return finalize_affine_impl<float>(part_dot, part_sq_a, part_sq_c, base, base_add, batch, tiles, n, x, x_batch_stride,
+                                       D, w, w_batch_stride, c, c_batch_stride, mean, var, stream);
+}
+int nsgp_svgp_colstats_finalize_affine_f64(const double* part_dot, const double* part_sq_a, const double* part_sq_c,
+                                           const double* base, double base_add, int64_t batch, int64_t tiles,
+                                           int64_t n, const double* x, int64_t x_batch_stride, int64_t D,
+                                           const double* w, int64_t w_batch_stride, const double* c,
+                                           int64_t c_batch_stride, double* mean, double* var, void* stream) {
+    return finalize_affine_impl<double>(part_dot, part_sq_a, part_sq_c, base, base_add, batch, tiles, n, x,
+                                        x_batch_stride, D, w, w_batch_stride, c, c_batch_stride, mean, var, stream);
+}
+int nsgp_rowdot_affine_f32(const float* A, const float* g, const float* gv, const float* x, int64_t x_batch_stride,
+                           int64_t D, int shared, int64_t batch, int64_t M, int64_t n, float* out, float* out_gv,
+                           float* out_x, float* out_1, void* stream) {
+    return rowdot_affine_impl<float>(A, g, gv, x, x_batch_stride, D, shared, batch, M, n, out, out_gv, out_x, out_1,
+                                     stream);
+}
+int nsgp_rowdot_affine_f64(const double* A, const double* g, const double* gv, const double* x, int64_t x_batch_stride,
+                           int64_t D, int shared, int64_t batch, int64_t M, int64_t n, double* out, double* out_gv,
+                           double* out_x, double* out_1, void* stream) {
+    return rowdot_affine_impl<double>(A, g, gv, x, x_batch_stride, D, shared, batch, M, n, out, out_gv, out_x, out_1,
+                                      stream);
 }
 int nsgp_rowdot_f32(const float* A, const float* g, int64_t batch, int64_t M, int64_t n, float* out, void* stream) {
     if (!A) return -1; if (!g) return -2; if (batch < 0) return -3; if (M < 0) return -4; if (n < 0) return -5;

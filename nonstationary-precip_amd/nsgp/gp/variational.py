@@ -14,6 +14,7 @@ from . import settings
 from .distributions import MultivariateNormal
 from .kernels import RBFKernel, ScaleKernel
 from .lazy import CholLazyTensor
+from .means import ConstantMean, LinearMean, ZeroMean
 from .module import Module
 
 
@@ -105,12 +106,29 @@ class VariationalStrategy(_VariationalStrategy):
         Z, ls, os_, m, Lq = self._flat_params()
         jitter = settings.variational_cholesky_jitter.value(x_flat.dtype)
         W64 = getattr(self, '_W64_shared', None)         # set by DeepGP.__call__ (one chain for all layers)
-        mean, var, _info = svgp_marginal(x_flat, Z, ls.contiguous(), os_.contiguous(), m, Lq, jitter=jitter,
-                                         chol_bwd_f64=settings.chol_bwd_f64.on(), W64=W64)
         b = Z.shape[0]
+        fused, mean_w, mean_c = self._affine_prior_mean(b, x_flat.shape[-1])
+        mean, var, _info = svgp_marginal(x_flat, Z, ls.contiguous(), os_.contiguous(), m, Lq, jitter=jitter,
+                                         chol_bwd_f64=settings.chol_bwd_f64.on(), W64=W64, mean_w=mean_w,
+                                         mean_c=mean_c)
+        if fused:
+            return mean, var
         xin = x_flat if b == 1 and self.inducing_points.dim() == 2 else x_flat.unsqueeze(0).expand(b, *x_flat.shape)
         prior_mean = self.model.mean_module(xin).reshape(b, -1)
         return mean + prior_mean, var
+
+    def _affine_prior_mean(self, b, D):
+        """(fused, weights, constant) of the layer's mean module when it is one of the stock affine means (exact types:
+        a subclass may override forward), in the layouts SVGPLayerFn takes; (False, None, None) otherwise."""
+        mm = getattr(self.model, 'mean_module', None)
+        if type(mm) is ZeroMean:
+            return True, None, None
+        if type(mm) is ConstantMean and mm.constant.numel() in (1, b):
+            return True, None, mm.constant.reshape(-1)
+        if type(mm) is LinearMean and mm.weights.shape[-2] == D and mm.weights.numel() in (D, b * D) \
+                and (mm.bias is None or mm.bias.numel() * D == mm.weights.numel()):
+            return True, mm.weights.reshape(-1, D), None if mm.bias is None else mm.bias.reshape(-1)
+        return False, None, None
 
     def full_covariance(self, x):
         """Dense q(f) covariance at x:(S,n,D) for a single-output GP (used only by predict / nlpd):

@@ -441,10 +441,35 @@ def _timed(launch, flops, dtype):
         launch()
 
 
-def svgp_project(W, Kzx, Lq, m, base):
+def _affine_args(affine, batch, n, ref):
+    """(x, w, c) of an affine prior mean -> pointer / stride arguments of the *_affine entry points.
+    x:(n,D) shared by the batch or (batch,n,D); w:(D,) shared or (batch,D) or None; c:(1,) shared or (batch,) or None."""
+    x, w, c = affine
+    x = _c(x)
+    D = x.shape[-1]
+    if x.shape[-2] != n or (x.dim() == 3 and x.shape[0] != batch) or x.dim() not in (2, 3):
+        raise BackendError('affine prior mean: x shape')
+    sxb = n * D if x.dim() == 3 else 0
+    swb = scb = 0
+    if w is not None:
+        w = _c(w.reshape(-1, D))
+        if w.shape[0] not in (1, batch):
+            raise BackendError('affine prior mean: weights shape')
+        swb = D if (w.shape[0] == batch and batch > 1) else 0
+    if c is not None:
+        c = _c(c.reshape(-1))
+        if c.shape[0] not in (1, batch):
+            raise BackendError('affine prior mean: constant shape')
+        scb = 1 if (c.shape[0] == batch and batch > 1) else 0
+    _chk(ref, x, *[t for t in (w, c) if t is not None])
+    return x, sxb, D, w, swb, c, scb
+
+
+def svgp_project(W, Kzx, Lq, m, base, base_add=0.0, affine=None):
     """Fused K6 forward: A = W Kzx, C = Lq^T A (triangular MFMA GEMMs) with the column statistics reduced in
     the GEMM epilogues.  W, Lq:(b,M,M) lower; Kzx:(b,M,n); m:(b,M); base:(b,).
-    Returns A, C, mean = A^T m, var = base + colsum(C^2 - A^2)."""
+    Returns A, C, mean = A^T m (+ the affine prior mean x w + c, `affine` = (x, w, c)), var = base + base_add +
+    colsum(C^2 - A^2)."""
     ref = _chk(W, Kzx, Lq, m, base)
     W, Kzx, Lq, m, base = _c(W), _c(Kzx), _c(Lq), _c(m), _c(base.reshape(-1))
     batch, M, n = Kzx.shape
@@ -462,14 +487,21 @@ def svgp_project(W, Kzx, Lq, m, base):
                              _p(part[0]), _p(part[1]), st), flops, ref.dtype)
     _timed(lambda: _lib.call(f'nsgp_svgp_tri_gemm_colstats_{sfx}', _p(Lq), 1, _p(A), None, batch, M, n, _p(C),
                              None, _p(part[2]), st), flops, ref.dtype)
-    _lib.call(f'nsgp_svgp_colstats_finalize_{sfx}', _p(part[0]), _p(part[1]), _p(part[2]), _p(base), batch, T, n,
-              _p(mean), _p(var), st)
+    if affine is None:
+        x = w = c = None
+        sxb = D = swb = scb = 0
+    else:
+        x, sxb, D, w, swb, c, scb = _affine_args(affine, batch, n, ref)
+    _lib.call(f'nsgp_svgp_colstats_finalize_affine_{sfx}', _p(part[0]), _p(part[1]), _p(part[2]), _p(base),
+              float(base_add), batch, T, n, _p(x), sxb, D, _p(w), swb, _p(c), scb, _p(mean), _p(var), st)
     return A, C, mean, var
 
 
-def svgp_project_bwd(Lq, m, A, C, gmean, gvar):
+def svgp_project_bwd(Lq, m, A, C, gmean, gvar, affine=None):
     """Adjoints of svgp_project w.r.t. A (total, through C as well), Lq and m:
-    Abar = 2 (Lq C) diag(gvar) + m gmean^T - 2 A diag(gvar);  Lqbar = tril(A diag(2 gvar) C^T);  mbar = A gmean."""
+    Abar = 2 (Lq C) diag(gvar) + m gmean^T - 2 A diag(gvar);  Lqbar = tril(A diag(2 gvar) C^T);  mbar = A gmean.
+    Also returns basebar = rowsum(gvar):(b,) and, with `affine` = (x, w, c) as in svgp_project, the gradients
+    (wbar, cbar) of the affine prior mean in the shapes of w / c (None where w / c is None)."""
     ref = _chk(Lq, m, A, C, gmean, gvar)
     Lq, m, A, C, gmean, gvar = _c(Lq), _c(m), _c(A), _c(C), _c(gmean), _c(gvar)
     batch, M, n = A.shape
@@ -482,14 +514,29 @@ def svgp_project_bwd(Lq, m, A, C, gmean, gvar):
     Lqbar = torch.empty_like(Lq)
     mbar = torch.empty_like(m)
     flops = 1.0 * M * M * n * batch
-    _lib.call(f'nsgp_rowdot_{sfx}', _p(A), _p(gmean), batch, M, n, _p(mbar), st)
+    basebar = torch.empty(batch, dtype=ref.dtype, device=ref.device)
+    wbar = cbar = None
+    if affine is None:
+        x, sxb, D, shared = None, 0, 0, 0
+    else:
+        x, sxb, D, w, swb, c, scb = _affine_args(affine, batch, n, ref)
+        shared = int(swb == 0 and scb == 0)
+        if w is not None and c is not None and batch > 1 and (swb == 0) != (scb == 0):
+            raise BackendError('affine prior mean: weights and constant must both be shared or both be per batch')
+        nb = 1 if shared else batch
+        if w is not None:
+            wbar = torch.empty((nb, D), dtype=ref.dtype, device=ref.device)
+        if c is not None:
+            cbar = torch.empty(nb, dtype=ref.dtype, device=ref.device)
+    _lib.call(f'nsgp_rowdot_affine_{sfx}', _p(A), _p(gmean), _p(gvar), _p(x) if wbar is not None else None, sxb, D,
+              shared, batch, M, n, _p(mbar), _p(basebar), _p(wbar), _p(cbar), st)
     _timed(lambda: _lib.call(f'nsgp_svgp_abar_{sfx}', _p(Lq), _p(C), _p(A), _p(m), _p(gmean), _p(gvar), batch, M, n,
                              _p(Abar), st), flops, ref.dtype)
     wsb = lib.nsgp_svgp_lqbar_workspace(batch, M, n, ref.element_size())
     ws = _ws(wsb, ref.device) if wsb else None
     _timed(lambda: _lib.call(f'nsgp_svgp_lqbar_{sfx}', _p(A), _p(C), _p(gvar), batch, M, n, _p(Lqbar), _p(ws),
                              ws.numel() if ws is not None else 0, st), flops, ref.dtype)
-    return Abar, Lqbar, mbar
+    return Abar, Lqbar, mbar, basebar, wbar, cbar
 
 
 def dgp_sample(mean, var, eps):

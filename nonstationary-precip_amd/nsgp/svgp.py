@@ -118,43 +118,57 @@ def whiten(groups, jitter=1e-4, chol_bwd_f64=True):
 
 
 class SVGPLayerFn(torch.autograd.Function):
-    """(x, Z, ls, os, m, Lq, W64) -> (mean_without_prior_mean:(b,n), var:(b,n))
+    """(x, Z, ls, os, m, Lq, W64, mean_w, mean_c) -> (mean:(b,n), var:(b,n))
 
     x:(n,D) shared by the b output GPs, or (b,n,D);  Z:(b,M,D)  ls:(b,D)  os:(b,)  m:(b,M)  Lq:(b,M,M)
     (only the lower triangle of Lq is used, like CholeskyVariationalDistribution.forward);
     W64:(b,M,M) = chol(Kzz)^-1 from WhitenFn (float64).  The dependence of Kzz on (Z, ls, os) flows
     through W64's gradient; this node differentiates the Kzx path.
+    mean_w:(D,) or (b,D) and mean_c:(1,) or (b,) are the weights / constant of an affine prior mean function
+    (gpytorch LinearMean / ConstantMean, models/dgps.py:40-43); either may be None.  The prior mean is added in the
+    kernel that assembles the column statistics and its gradients come out of the `rowdot` launch of the backward,
+    so the mean module costs no launches of its own.
     """
 
     @staticmethod
-    def forward(ctx, x, Z, ls, os_, m, Lq, W64):
+    def forward(ctx, x, Z, ls, os_, m, Lq, W64, mean_w, mean_c):
         W = ops.cast(W64, x.dtype)
         Kzx = ops.rbf_build(Z, x, ls, os_)                                       # (b,M,n)
-        A, C, mean, var = ops.svgp_project(W, Kzx, Lq, m, os_ + VAR_JITTER)      # 2 GEMMs, stats in the epilogues
-        ctx.save_for_backward(x, Z, ls, os_, m, Lq, W, Kzx, A, C)
+        affine = None if (mean_w is None and mean_c is None) else (x, mean_w, mean_c)
+        A, C, mean, var = ops.svgp_project(W, Kzx, Lq, m, os_, base_add=VAR_JITTER, affine=affine)   # 2 GEMMs
+        ctx.save_for_backward(x, Z, ls, os_, m, Lq, W, Kzx, A, C, mean_w, mean_c)
         ctx.w_dtype = W64.dtype
         return mean, var
 
     @staticmethod
     def backward(ctx, gmean, gvar):
-        x, Z, ls, os_, m, Lq, W, Kzx, A, C = ctx.saved_tensors
-        Abar, Lqbar, mbar = ops.svgp_project_bwd(Lq, m, A, C, gmean.contiguous(), gvar.contiguous())
+        x, Z, ls, os_, m, Lq, W, Kzx, A, C, mean_w, mean_c = ctx.saved_tensors
+        gmean = gmean.contiguous()
+        affine = None if (mean_w is None and mean_c is None) else (x, mean_w, mean_c)
+        Abar, Lqbar, mbar, basebar, wbar, cbar = ops.svgp_project_bwd(Lq, m, A, C, gmean, gvar.contiguous(),
+                                                                      affine=affine)
         Kzxbar = ops.gemm(W, Abar, ta=True, flags=GEMM_A_UPPER)                  # W^T Abar
         Wbar = ops.gemm(Abar, Kzx, tb=True, flags=GEMM_C_LOWER)                  # tril(Abar Kzx^T)
         need_x = ctx.needs_input_grad[0]
         gZ, gx, gls, gos = ops.rbf_build_bwd(Z, x, ls, os_, Kzxbar, need_x1=True, need_x2=need_x)
-        gos = gos + gvar.sum(-1)
-        if need_x and x.dim() == 2:
-            gx = gx.sum(0)
+        gos = gos + basebar
+        if need_x:
+            if mean_w is not None:                       # d(prior mean)/dx = w  (deeper layers of a tied stack only)
+                gx = gx + gmean.unsqueeze(-1) * mean_w.reshape(-1, 1, x.shape[-1])
+            if x.dim() == 2:
+                gx = gx.sum(0)
         return (gx if need_x else None, gZ, gls.reshape(ls.shape), gos.reshape(os_.shape), mbar, Lqbar,
-                ops.cast(Wbar, ctx.w_dtype))
+                ops.cast(Wbar, ctx.w_dtype),
+                None if mean_w is None else wbar.reshape(mean_w.shape),
+                None if mean_c is None else cbar.reshape(mean_c.shape))
 
 
-def svgp_marginal(x, Z, ls, os_, m, Lq, jitter=1e-4, chol_bwd_f64=True, W64=None):
-    """mean (without the prior mean function) and variance of q(f) at x for b whitened SVGPs.
+def svgp_marginal(x, Z, ls, os_, m, Lq, jitter=1e-4, chol_bwd_f64=True, W64=None, mean_w=None, mean_c=None):
+    """mean and variance of q(f) at x for b whitened SVGPs; the mean excludes the prior mean function unless its
+    affine parameters are passed (mean_w: LinearMean weights (D,) / (b,D), mean_c: constant or bias (1,) / (b,)).
     Returns (mean, var, info); pass W64 (from `whiten`) to share one factorisation chain across layers."""
     info = None
     if W64 is None:
         (W64,), info = whiten([(Z, ls, os_)], jitter, chol_bwd_f64)
-    mean, var = SVGPLayerFn.apply(x, Z, ls, os_, m, Lq, W64)
+    mean, var = SVGPLayerFn.apply(x, Z, ls, os_, m, Lq, W64, mean_w, mean_c)
     return mean, var, info

@@ -112,7 +112,8 @@ def test_fused_projection_ops_match_dense_formulas(dt, b, M, n):
     assert torch.allclose(C.cpu().double(), C_ref, **tol)
     assert torch.allclose(mean.cpu().double(), mean_ref, **tol)
     assert torch.allclose(var.cpu().double(), var_ref, **tol)
-    Abar, Lqbar, mbar = ops.svgp_project_bwd(dev(Lq + junk), dev(m), A, C, dev(gm), dev(gv))
+    Abar, Lqbar, mbar, basebar, wbar, cbar = ops.svgp_project_bwd(dev(Lq + junk), dev(m), A, C, dev(gm), dev(gv))
+    assert wbar is None and cbar is None
     A_, C_ = A.cpu().double(), C.cpu().double()           # adjoints evaluated at the device's own A, C
     Abar_ref = 2 * (Lq @ C_) * gv[:, None, :] + m[:, :, None] * gm[:, None, :] - 2 * A_ * gv[:, None, :]
     Lqbar_ref = torch.tril(torch.einsum('bkj,bj,blj->bkl', A_, 2 * gv, C_))
@@ -122,6 +123,68 @@ def test_fused_projection_ops_match_dense_formulas(dt, b, M, n):
     assert torch.allclose(Lqbar.cpu().double(), Lqbar_ref, **tolb)
     assert torch.allclose(mbar.cpu().double(), mbar_ref, **tolb)
     assert float(torch.triu(Lqbar, 1).abs().max()) == 0.0 if M > 1 else True
+    assert torch.allclose(basebar.cpu().double(), gv.sum(-1), **tolb)
+
+
+@pytest.mark.parametrize('dt', [F64, F32])
+@pytest.mark.parametrize('b,M,n,D,xb,shared,has_w,has_c', [
+    (2, 40, 333, 3, False, True, True, True),        # models/dgps.py hidden layer: LinearMean shared by the output GPs
+    (1, 64, 1000, 2, False, True, False, True),      # last layer: ConstantMean
+    (3, 33, 130, 2, True, False, True, True),        # per-GP inputs, weights and bias
+    (2, 16, 65, 4, False, False, False, True),       # ConstantMean(batch_shape=[b])
+    (2, 16, 65, 1, True, True, True, False),         # LinearMean(bias=False)
+])
+def test_affine_prior_mean_is_folded_into_the_projection(dt, b, M, n, D, xb, shared, has_w, has_c):
+    """colstats_finalize_affine / rowdot_affine: the prior mean x w + c added while the column statistics are assembled,
+    `base_add` on the variance, and the gradients of w, c and `base` from the rowdot launch -- against dense formulas,
+    with shared and per-batch parameters and shared / per-batch inputs."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from nsgp import ops
+    g = _g(77 + n + D)
+    W = torch.tril(torch.randn(b, M, M, generator=g, dtype=F64)) / M ** 0.5
+    Lq = torch.tril(0.3 * torch.randn(b, M, M, generator=g, dtype=F64)) + torch.eye(M, dtype=F64)
+    K = torch.randn(b, M, n, generator=g, dtype=F64)
+    m = torch.randn(b, M, generator=g, dtype=F64)
+    base = torch.rand(b, generator=g, dtype=F64) + 0.5
+    x = torch.randn(*((b,) if xb else ()), n, D, generator=g, dtype=F64)
+    nb = 1 if shared else b
+    w = torch.randn(nb, D, generator=g, dtype=F64) if has_w else None
+    c = torch.randn(nb, generator=g, dtype=F64) if has_c else None
+    gm = torch.randn(b, n, generator=g, dtype=F64)
+    gv = torch.randn(b, n, generator=g, dtype=F64)
+    dev = lambda t: None if t is None else t.to(dt).cuda()
+    aff = (dev(x), dev(w), dev(c))
+    A, C, mean, var = ops.svgp_project(dev(W), dev(K), dev(Lq), dev(m), dev(base), base_add=1e-4, affine=aff)
+    A_ref = W @ K
+    C_ref = Lq.transpose(-1, -2) @ A_ref
+    xe = x if xb else x.unsqueeze(0).expand(b, n, D)
+    prior = torch.zeros(b, n, dtype=F64)
+    if has_w:
+        prior = prior + torch.einsum('bnd,bd->bn', xe, w.expand(b, D))
+    if has_c:
+        prior = prior + c.expand(b)[:, None]
+    mean_ref = torch.einsum('bkj,bk->bj', A_ref, m) + prior
+    var_ref = base[:, None] + 1e-4 + (C_ref ** 2).sum(1) - (A_ref ** 2).sum(1)
+    tol = dict(rtol=1e-10, atol=1e-10) if dt == F64 else dict(rtol=2e-4, atol=2e-4 * M ** 0.5)
+    assert torch.allclose(mean.cpu().double(), mean_ref, **tol)
+    assert torch.allclose(var.cpu().double(), var_ref, **tol)
+    _, _, mbar, basebar, wbar, cbar = ops.svgp_project_bwd(dev(Lq), dev(m), A, C, dev(gm), dev(gv), affine=aff)
+    tolb = dict(rtol=1e-9, atol=1e-9) if dt == F64 else dict(rtol=5e-4, atol=5e-4 * n ** 0.5)
+    assert torch.allclose(mbar.cpu().double(), torch.einsum('bkj,bj->bk', A.cpu().double(), gm), **tolb)
+    assert torch.allclose(basebar.cpu().double(), gv.sum(-1), **tolb)
+    if has_w:
+        wref = torch.einsum('bnd,bn->bd', xe, gm)
+        assert wbar.shape == (nb, D)
+        assert torch.allclose(wbar.cpu().double(), wref.sum(0, keepdim=True) if shared else wref, **tolb)
+    else:
+        assert wbar is None
+    if has_c:
+        cref = gm.sum(-1)
+        assert cbar.shape == (nb,)
+        assert torch.allclose(cbar.cpu().double(), cref.sum(0, keepdim=True) if shared else cref, **tolb)
+    else:
+        assert cbar is None
 
 
 def test_non_positive_definite_kzz_is_reported_when_asked():
