@@ -493,6 +493,18 @@ def test_empty_inputs_are_no_ops_and_bad_arguments_report_their_index(ops):
     # fused SVGP GEMM: empty batch
     assert lib.nsgp_svgp_tri_gemm_colstats_f32(P(A), 0, P(A), None, 0, 4, 4, P(C), None, P(C), st) == 0
     assert lib.nsgp_svgp_tri_gemm_colstats_f32(P(A), 2, P(A), None, 1, 4, 4, P(C), None, P(C), st) == -2   # trans not 0/1
+    # affine finalize / rowdot: empty problems, linear part without x (arg 9), D beyond NSGP_MAX_DIM (arg 11 / 6)
+    v = torch.zeros(8, device='cuda', dtype=F32)
+    fin = lambda batch, n, x, D, w: lib.nsgp_svgp_colstats_finalize_affine_f32(
+        P(A), P(A), P(A), P(v), 0.0, batch, 1, n, x, 0, D, w, 0, None, 0, P(v), P(C), st)
+    assert fin(0, 4, None, 0, None) == 0 and fin(1, 0, None, 0, None) == 0
+    assert fin(1, 4, None, 2, P(v)) == -9
+    assert fin(1, 4, P(A), 1000, P(v)) == -11
+    rd = lambda batch, D, x, ox: lib.nsgp_rowdot_affine_f32(P(A), P(v), None, x, 0, D, 1, batch, 2, 2, P(C), None, ox,
+                                                          None, st)
+    assert rd(0, 0, None, None) == 0
+    assert rd(1, 1000, None, None) == -6
+    assert rd(1, 2, None, P(v)) == -13                                  # weight gradient asked for without x
     # a non-positive-definite matrix is reported LAPACK-style in info (1-based index of the failing minor)
     Bad = torch.eye(70, device='cuda', dtype=F64)
     Bad[65, 65] = -1.0
