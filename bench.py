@@ -299,7 +299,7 @@ def main():
         eps.start_step(0, row0=lo)
         opt.zero_grad()
         out = model(x_in)
-        loss = -dp_objective(mll, out, y_in, gbatch, world * share)
+        loss = dp_objective(mll, out, y_in, gbatch, world * share, negate=True)        # = -(rank's share of the ELBO)
         loss.backward()
         opt.bucket.gather_grads()            # one multi-tensor copy into the flat gradient bucket
         return loss.detach()

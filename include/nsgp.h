@@ -326,6 +326,12 @@ int nsgp_kl_whitened_total_fwd_f32(const float* m, const float* Lq, int64_t batc
                                    void* ws, size_t ws_bytes, void* stream);
 int nsgp_kl_whitened_total_fwd_f64(const double* m, const double* Lq, int64_t batch, int64_t M, double scale,
                                    double* out, void* ws, size_t ws_bytes, void* stream);
+/* out[0] = addin[0] + scale * sum_b KL_b: the KL terms of several layers (and the likelihood term) chain into ONE
+ * scalar without separate additions (addin may be NULL; with addin given, batch must be > 0). */
+int nsgp_kl_whitened_total_acc_fwd_f32(const float* m, const float* Lq, int64_t batch, int64_t M, float scale,
+                                       const float* addin, float* out, void* ws, size_t wsb, void* stream);
+int nsgp_kl_whitened_total_acc_fwd_f64(const double* m, const double* Lq, int64_t batch, int64_t M, double scale,
+                                       const double* addin, double* out, void* ws, size_t wsb, void* stream);
 int nsgp_kl_whitened_total_bwd_f32(const float* m, const float* Lq, int64_t batch, int64_t M, float scale,
                                    const float* gout, float* gm, float* gLq, void* stream);
 int nsgp_kl_whitened_total_bwd_f64(const double* m, const double* Lq, int64_t batch, int64_t M, double scale,

@@ -228,14 +228,15 @@ __global__ void sample_bwd_kernel(const T* __restrict__ var, const T* __restrict
 
 template <typename T>
 __global__ __launch_bounds__(256) void reduce_final_kernel(const T* __restrict__ part, int64_t nparts, int64_t nout,
-                                                           T scale, T add, T* __restrict__ out) {
+                                                           T scale, T add, T* __restrict__ out,
+                                                           const T* __restrict__ add_dev = nullptr) {
     __shared__ T lds[4];
     const int64_t o = blockIdx.x;
     if (o >= nout) return;
     T s = T(0);
     for (int64_t t = threadIdx.x; t < nparts; t += 256) s += part[o * nparts + t];
     s = block_sum_256(s, lds);
-    if (threadIdx.x == 0) out[o] = scale * s + add;
+    if (threadIdx.x == 0) out[o] = scale * s + add + (add_dev ? add_dev[o] : T(0));
 }
 
 // ---- gaussian expected log-likelihood (per sample row s) -------------------------------------------
@@ -414,7 +415,7 @@ int gauss_bwd_impl(const T* y, const T* mu, const T* v, const T* noise, int64_t 
 
 template <typename T>
 int kl_fwd_impl(const T* m, const T* Lq, int64_t batch, int64_t M, T* out, void* ws, size_t wsb, void* stream,
-                bool total = false, T scale = T(1)) {
+                bool total = false, T scale = T(1), const T* addin = nullptr) {
     if (!m) return -1; if (!Lq) return -2; if (batch < 0) return -3; if (M < 0) return -4; if (!out) return -5;
     if (batch == 0) return 0;
     int64_t nblk = cdiv64(M * M, 1024); if (nblk > 256) nblk = 256; if (nblk < 1) nblk = 1;
@@ -423,7 +424,7 @@ int kl_fwd_impl(const T* m, const T* Lq, int64_t batch, int64_t M, T* out, void*
     hipLaunchKernelGGL((kl_part_kernel<T>), dim3((unsigned)nblk, (unsigned)batch), dim3(256), 0, st, m, Lq, M, (T*)ws);
     if (total)                                           // out[0] = scale * sum_b KL_b
         hipLaunchKernelGGL((reduce_final_kernel<T>), dim3(1), dim3(256), 0, st, (const T*)ws, batch * nblk, (int64_t)1,
-                           T(0.5) * scale, T(-0.5) * T(M) * T(batch) * scale, out);
+                           T(0.5) * scale, T(-0.5) * T(M) * T(batch) * scale, out, addin);
     else
         hipLaunchKernelGGL((reduce_final_kernel<T>), dim3((unsigned)batch), dim3(256), 0, st, (const T*)ws, nblk, batch,
                            T(0.5), T(-0.5) * T(M), out);
@@ -648,6 +649,16 @@ int nsgp_kl_whitened_total_fwd_f32(const float* m, const float* Lq, int64_t batc
 int nsgp_kl_whitened_total_fwd_f64(const double* m, const double* Lq, int64_t batch, int64_t M, double scale,
                                    double* out, void* ws, size_t wsb, void* stream) {
     return kl_fwd_impl<double>(m, Lq, batch, M, out, ws, wsb, stream, true, scale);
+}
+int nsgp_kl_whitened_total_acc_fwd_f32(const float* m, const float* Lq, int64_t batch, int64_t M, float scale,
+                                       const float* addin, float* out, void* ws, size_t wsb, void* stream) {
+    if (batch == 0) return addin ? -3 : 0;               // nothing would write out = addin
+    return kl_fwd_impl<float>(m, Lq, batch, M, out, ws, wsb, stream, true, scale, addin);
+}
+int nsgp_kl_whitened_total_acc_fwd_f64(const double* m, const double* Lq, int64_t batch, int64_t M, double scale,
+                                       const double* addin, double* out, void* ws, size_t wsb, void* stream) {
+    if (batch == 0) return addin ? -3 : 0;
+    return kl_fwd_impl<double>(m, Lq, batch, M, out, ws, wsb, stream, true, scale, addin);
 }
 int nsgp_kl_whitened_total_bwd_f32(const float* m, const float* Lq, int64_t batch, int64_t M, float scale,
                                    const float* gout, float* gm, float* gLq, void* stream) {

@@ -44,20 +44,22 @@ class PhiloxEps:
                                  step_dev=self.step_dev)
 
 
-def dp_objective(mll, output, y_local, batch_global, world):
-    """Rank-local share of DeepApproximateMLL(VariationalELBO(...))(output, y): see module docstring."""
+def dp_objective(mll, output, y_local, batch_global, world, negate=False):
+    """Rank-local share of DeepApproximateMLL(VariationalELBO(...))(output, y): see module docstring.
+    negate=True returns the loss (minus the objective) directly, sparing the negation kernels."""
     base = getattr(mll, 'base_mll', mll)
     b_local = y_local.shape[-1]
     mean = output.mean
     if mean.dim() == 2:
         from .gp.mlls import fused_dsvi_objective
         fused = fused_dsvi_objective(base, output, y_local, 1.0 / (batch_global * mean.shape[0]),
-                                     base.beta / (base.num_data * world))
+                                     base.beta / (base.num_data * world), negate=negate)
         if fused is not None:
             return fused
     ell = base._log_likelihood_term(output, y_local, num_batch=b_local)            # (S,)
     kl = base.model.variational_strategy.kl_divergence() / (base.num_data / base.beta)
-    return ((b_local / batch_global) * ell - kl / world).mean(0)
+    obj = ((b_local / batch_global) * ell - kl / world).mean(0)
+    return -obj if negate else obj
 
 
 class DataParallel:

@@ -98,7 +98,7 @@ class VariationalELBO(_ApproximateMarginalLogLikelihood):
         return self.likelihood.expected_log_prob(target, variational_dist_f, **kwargs).sum(-1) / B
 
 
-def fused_dsvi_objective(base, approximate_dist_f, target, ell_scale, kl_scale):
+def fused_dsvi_objective(base, approximate_dist_f, target, ell_scale, kl_scale, negate=False):
     """ell_scale * sum_s sum_i E_q log p(y_i | f_si)  -  kl_scale * sum_j KL_j  as ONE scalar with a short launch
     chain (two reductions per term, device-resident upstream gradients), or None when the fast path does not
     apply (non-Gaussian likelihood, CPU tensors, priors / added-loss terms, non-whitened strategies).
@@ -119,9 +119,10 @@ def fused_dsvi_objective(base, approximate_dist_f, target, ell_scale, kl_scale):
         if vd is None or not hasattr(vd, 'chol_variational_covar') or not hasattr(st, 'whiten_group'):
             return None
         pairs.append((vd.variational_mean, vd.chol_variational_covar))
-    total = ops.GaussEllTotalFn.apply(target, mean, var, lik.noise, float(ell_scale))
-    for m, Lq in pairs:
-        total = total + ops.KlWhitenedTotalFn.apply(m, Lq, -float(kl_scale))
+    sign = -1.0 if negate else 1.0                       # negate: the loss -ELBO itself, no separate negation
+    total = ops.GaussEllTotalFn.apply(target, mean, var, lik.noise, sign * float(ell_scale))
+    for m, Lq in pairs:                                  # each KL term is added into the running scalar by its own kernel
+        total = ops.KlWhitenedTotalFn.apply(m, Lq, -sign * float(kl_scale), total)
     return total
 
 

@@ -896,23 +896,28 @@ class GaussEllTotalFn(torch.autograd.Function):
 
 
 class KlWhitenedTotalFn(torch.autograd.Function):
-    """Scalar  scale * sum_b KL(N(m_b, Lq_b Lq_b^T) || N(0, I)); backward reads the upstream gradient on the device."""
+    """Scalar  addin + scale * sum_b KL(N(m_b, Lq_b Lq_b^T) || N(0, I))  (addin: optional scalar tensor, so the terms of
+    an objective chain without separate additions); backward reads the upstream gradient on the device."""
 
     @staticmethod
-    def forward(ctx, m, Lq, scale):
+    def forward(ctx, m, Lq, scale, addin=None):
         ref = _chk(m, Lq)
         m2, L2 = _c(m), _c(Lq)
         if m2.dim() == 1:
             m2, L2 = m2.unsqueeze(0), L2.unsqueeze(0)
         batch, M = m2.shape
-        if L2.shape != (batch, M, M):
+        if L2.shape != (batch, M, M) or batch == 0:
             raise BackendError('kl_whitened_total: shapes')
+        if addin is not None:
+            _chk(ref, addin)
+            if addin.numel() != 1:
+                raise BackendError('kl_whitened_total: addin must be a scalar')
         out = torch.empty(1, dtype=ref.dtype, device=ref.device)
         ws = _red_ws(ref)
-        _lib.call(f'nsgp_kl_whitened_total_fwd_{_sfx(ref)}', _p(m2), _p(L2), batch, M, float(scale), _p(out), _p(ws),
-                  ws.numel(), _stream())
+        _lib.call(f'nsgp_kl_whitened_total_acc_fwd_{_sfx(ref)}', _p(m2), _p(L2), batch, M, float(scale),
+                  None if addin is None else _p(_c(addin).reshape(1)), _p(out), _p(ws), ws.numel(), _stream())
         ctx.save_for_backward(m2, L2)
-        ctx.scale, ctx.shapes = float(scale), (m.shape, Lq.shape)
+        ctx.scale, ctx.shapes, ctx.has_addin = float(scale), (m.shape, Lq.shape), addin is not None
         return out.reshape(())
 
     @staticmethod
@@ -922,7 +927,7 @@ class KlWhitenedTotalFn(torch.autograd.Function):
         gm, gL = torch.empty_like(m2), torch.empty_like(L2)
         _lib.call(f'nsgp_kl_whitened_total_bwd_{_sfx(m2)}', _p(m2), _p(L2), batch, M, ctx.scale, _p(_c(g).reshape(1)),
                   _p(gm), _p(gL), _stream())
-        return gm.reshape(ctx.shapes[0]), gL.reshape(ctx.shapes[1]), None
+        return gm.reshape(ctx.shapes[0]), gL.reshape(ctx.shapes[1]), None, (g if ctx.has_addin else None)
 
 
 class DgpSampleFn(torch.autograd.Function):

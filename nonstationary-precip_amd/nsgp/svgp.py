@@ -156,7 +156,7 @@ class SVGPLayerFn(torch.autograd.Function):
             if mean_w is not None:                       # d(prior mean)/dx = w  (deeper layers of a tied stack only)
                 gx = gx + gmean.unsqueeze(-1) * mean_w.reshape(-1, 1, x.shape[-1])
             if x.dim() == 2:
-                gx = gx.sum(0)
+                gx = gx[0] if gx.shape[0] == 1 else gx.sum(0)
         return (gx if need_x else None, gZ, gls.reshape(ls.shape), gos.reshape(os_.shape), mbar, Lqbar,
                 ops.cast(Wbar, ctx.w_dtype),
                 None if mean_w is None else wbar.reshape(mean_w.shape),
