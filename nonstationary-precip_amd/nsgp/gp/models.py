@@ -194,10 +194,11 @@ class DeepGP(GP):
                 for s in strategies:
                     s._maybe_init()
                 groups = [s.whiten_group() for s in strategies]
-                Ws, _info = whiten(groups, settings.variational_cholesky_jitter.value(args[0].dtype),
-                                   settings.chol_bwd_f64.on())
-                for s, W in zip(strategies, Ws):
+                Ws, _info, passed = whiten(groups, settings.variational_cholesky_jitter.value(args[0].dtype),
+                                           settings.chol_bwd_f64.on(), passthrough=True)
+                for s, W, zlo in zip(strategies, Ws, passed):
                     s._W64_shared = W
+                    s._kernel_params_shared = zlo            # (Z, ls, os) routed through the whitening node
                 shared = True
             try:
                 return super().__call__(*args, **kwargs)
@@ -205,6 +206,7 @@ class DeepGP(GP):
                 if shared:
                     for s in strategies:
                         s._W64_shared = None
+                        s._kernel_params_shared = None
 
 
 class DeepLikelihood(GaussianLikelihood):

@@ -106,6 +106,9 @@ class VariationalStrategy(_VariationalStrategy):
         Z, ls, os_, m, Lq = self._flat_params()
         jitter = settings.variational_cholesky_jitter.value(x_flat.dtype)
         W64 = getattr(self, '_W64_shared', None)         # set by DeepGP.__call__ (one chain for all layers)
+        routed = getattr(self, '_kernel_params_shared', None)
+        if W64 is not None and routed is not None:
+            Z, ls, os_ = routed                          # same values; gradients return through the whitening node
         b = Z.shape[0]
         fused, mean_w, mean_c = self._affine_prior_mean(b, x_flat.shape[-1])
         mean, var, _info = svgp_marginal(x_flat, Z, ls.contiguous(), os_.contiguous(), m, Lq, jitter=jitter,

@@ -28,7 +28,10 @@ class WhitenFn(torch.autograd.Function):
     """W[g] = chol(os_g RBF(Z_g, Z_g; ls_g) + jitter I)^-1 in float64 for a list of GP groups.
 
     inputs: jitter, chol_bwd_f64, then (Z_i:(b_i,M,D_i), ls_i:(b_i,D_i), os_i:(b_i,)) per group, all with
-    the same M.  Output: W64:(sum b_i, M, M) float64 and info:(sum b_i,).  The Gram matrices are built
+    the same M.  Outputs: W64_i:(b_i, M, M) float64 per group, info:(sum b_i,), then the parameters again
+    (Z_i, ls_i, os_i pass-throughs).  A layer that takes its kernel parameters from the pass-throughs sends its Kzx-path
+    gradients back through this node, where they join the Kzz-path gradients in one multi-tensor add instead of six
+    accumulation launches of the autograd engine.  The Gram matrices are built
     per group (the input dimension differs between layers), then ONE batched potrf + trtri chain
     factors them all; the adjoint  Kbar = -1/2 W^T (Phi(B) + Phi(B)^T) W,  B = tril(Wbar) W^T  is three
     batched MFMA GEMMs.
@@ -63,11 +66,13 @@ class WhitenFn(torch.autograd.Function):
         for b in ctx.sizes:                      # one output per group (views of the batched result)
             outs.append(W64[off:off + b])
             off += b
-        return (*outs, info)
+        return (*outs, info, *[t.view_as(t) for t in flat])
 
     @staticmethod
     def backward(ctx, *gouts):
         W64, *flat = ctx.saved_tensors
+        ng = len(ctx.sizes)
+        gpass = gouts[ng + 1:]                               # gradients that came in through the pass-throughs
         parts = []
         for gi, b in enumerate(ctx.sizes):
             g = gouts[gi]
@@ -99,13 +104,19 @@ class WhitenFn(torch.autograd.Function):
         dst = [o for g, o in zip(grads[2:], outs) if o is not g]
         if dst:
             torch._foreach_copy_(dst, src)
+        extra = [(o, g) for o, g in zip(outs, gpass) if g is not None]
+        if extra:
+            torch._foreach_add_([o for o, _ in extra], [g.reshape(o.shape) for o, g in extra])
         return (None, None, *outs)
 
 
-def whiten(groups, jitter=1e-4, chol_bwd_f64=True):
-    """groups: list of (Z:(b,M,D), ls:(b,D), os:(b,)).  Returns (list of W64:(b,M,M) per group, info)."""
+def whiten(groups, jitter=1e-4, chol_bwd_f64=True, passthrough=False):
+    """groups: list of (Z:(b,M,D), ls:(b,D), os:(b,)).  Returns (list of W64:(b,M,M) per group, info); with
+    passthrough=True also the list of (Z, ls, os) pass-through triples a layer should build its Kzx from (WhitenFn)."""
     flat = [t for g in groups for t in g]
-    *Ws, info = WhitenFn.apply(float(jitter), bool(chol_bwd_f64), *flat)
+    res = WhitenFn.apply(float(jitter), bool(chol_bwd_f64), *flat)
+    ng = len(groups)
+    Ws, info, rest = res[:ng], res[ng], res[ng + 1:]
     from .gp import settings
     if settings.check_variational_cholesky.on():
         bad = info.nonzero()
@@ -114,6 +125,8 @@ def whiten(groups, jitter=1e-4, chol_bwd_f64=True):
             b = int(bad[0, 0])
             raise NotPSDError(f'Kzz + {jitter:g} I of GP {b} (of {info.numel()} in the whitening chain) is not positive '
                               f'definite: leading minor {int(info[b])} failed')
+    if passthrough:
+        return list(Ws), info, [tuple(rest[3 * i:3 * i + 3]) for i in range(ng)]
     return list(Ws), info
 
 
@@ -169,6 +182,6 @@ def svgp_marginal(x, Z, ls, os_, m, Lq, jitter=1e-4, chol_bwd_f64=True, W64=None
     Returns (mean, var, info); pass W64 (from `whiten`) to share one factorisation chain across layers."""
     info = None
     if W64 is None:
-        (W64,), info = whiten([(Z, ls, os_)], jitter, chol_bwd_f64)
+        (W64,), info, ((Z, ls, os_),) = whiten([(Z, ls, os_)], jitter, chol_bwd_f64, passthrough=True)
     mean, var = SVGPLayerFn.apply(x, Z, ls, os_, m, Lq, W64, mean_w, mean_c)
     return mean, var, info
