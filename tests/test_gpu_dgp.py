@@ -129,6 +129,30 @@ def test_dsvi_elbo_and_gradients_match_oracle(num_layers, D, M, B, S, chol_bwd_f
     print('max grad rel err', chol_bwd_f64, max(errs.values()), max(errs, key=errs.get))
 
 
+def test_negated_data_parallel_objective_is_minus_the_objective():
+    """nsgp.dist.dp_objective(negate=True) (what bench.py back-propagates) == -dp_objective(), value and gradients."""
+    _need_gpu()
+    from nsgp.dist import dp_objective
+    from nsgp.gp.mlls import DeepApproximateMLL, VariationalELBO
+    model, settings = _build(1, 3, 40, 140)
+    g = torch.Generator().manual_seed(3)
+    x, y = torch.randn(100, 3, generator=g).cuda(), torch.randn(100, generator=g).cuda()
+    eps = [torch.randn(3, 100, 2, generator=g)]
+    mll = DeepApproximateMLL(VariationalELBO(model.likelihood, model, 1234))
+    model.train()
+    vals, grads = [], []
+    for negate in (False, True):
+        model.zero_grad()
+        with settings.num_likelihood_samples(3), settings.eps_provider(_FixedEps(eps)):
+            obj = dp_objective(mll, model(x), y, 100, 1, negate=negate)
+            obj.backward()
+        vals.append(float(obj.detach()))
+        grads.append([p.grad.detach().clone() for p in model.parameters()])
+    assert vals[1] == pytest.approx(-vals[0], rel=1e-6)
+    for a, b in zip(*grads):
+        assert torch.allclose(a, -b, rtol=1e-5, atol=1e-7)
+
+
 def test_cfg5_three_layer_m2048_three_output_dims_matches_oracle():
     """BASELINE configs[4] shape at a reduced minibatch: DeepGP(num_layers=2) = the tied hidden layer applied twice
     + the last layer, M=2048 inducing points, 3-D inputs, so `num_output_dims` has to be 3 (the tied layer feeds
