@@ -247,6 +247,9 @@ def main():
                     help='weak (default): every GPU takes its own 4096-row minibatch per iteration (global batch '
                          '4096 x N), value = N x iterations/s; strong: ONE 4096-row minibatch is split over the N GPUs, '
                          'value = iterations/s.  Identical at N=1.')
+    ap.add_argument('--split-graph', action='store_true',
+                    help='analysis only (N=1): replay the step as the TWO graphs an N>1 run uses (forward+backward, then Adam) '
+                         'with the eager gradient all-reduce call between them (a no-op at N=1), to price the split')
     ap.add_argument('--rank-share', type=int, default=1, metavar='G',
                     help='analysis only: run ONE rank\'s share of a G-rank job on this GPU (rows [0, 4096/G) of every '
                          'minibatch, the objective scaled as on rank 0 of G; no collective).  The JSON line is marked '
@@ -326,7 +329,7 @@ def main():
         if use_graph:
             from nsgp.graph import GraphedCallable
             p0 = opt.bucket.flat_p.detach().clone()      # graph warm-up / capture runs real steps: undo them below
-            if world == 1:
+            if world == 1 and not args.split_graph:
                 g_step = GraphedCallable(whole_step)                 # forward + ELBO + backward + Adam: one graph
             else:
                 g_fb = GraphedCallable(fwd_bwd)                      # all-reduce stays an eager RCCL call
@@ -346,7 +349,7 @@ def main():
                 loss = fwd_bwd()
                 dp.allreduce_grads(gather=False)
                 adam_step()
-            elif world == 1:
+            elif world == 1 and not args.split_graph:
                 loss = g_step()
             else:
                 loss = g_fb()
@@ -405,6 +408,7 @@ def main():
                        'global_batch': gbatch, 'N': N_DATA, 'parallelism': f'dp{world}',
                        'kzz_cholesky_dtype': 'f64', 'hipgraph': bool(use_graph)},
             'iterations_per_sec': round(args.steps / elapsed, 3),
+            **({'analysis_split_graph': 'two graph replays per step, as in an N>1 run'} if args.split_graph else {}),
             **({'analysis': f'one rank\'s share of a {share}-rank job (rows [0, {hi - lo}) of each minibatch), '
                             'no collective; NOT a --gpus result'} if share > 1 else {}),
             'final_loss': round(final_loss, 5),
