@@ -188,21 +188,23 @@ def test_affine_prior_mean_is_folded_into_the_projection(dt, b, M, n, D, xb, sha
 
 
 def test_non_positive_definite_kzz_is_reported_when_asked():
-    """settings.check_variational_cholesky: duplicate inducing points with zero jitter make Kzz singular; the default
-    path stays sync-free (NaNs), the checked path raises like gpytorch's psd_safe_cholesky would."""
+    """settings.check_variational_cholesky: a Kzz that is not positive definite leaves the default path sync-free (info
+    set, NaNs downstream) and makes the checked path raise like gpytorch's psd_safe_cholesky would; duplicate inducing
+    points (a singular Kzz) are repaired by the default jitter.  The non-PD case uses a negative output scale so that
+    the first pivot is -1: an exactly singular matrix passes or fails on the sign of a rounding error."""
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     from nsgp.gp import settings
     from nsgp.gp.utils.cholesky import NotPSDError
     from nsgp.svgp import whiten
-    Z = torch.randn(1, 70, 2, dtype=F32).cuda()
+    Z = torch.randn(1, 70, 2, dtype=F32, generator=_g(5)).cuda()
     Z[0, 69] = Z[0, 3]
     ls = torch.ones(1, 2, device='cuda')
     os_ = torch.ones(1, device='cuda')
-    Ws, info = whiten([(Z, ls, os_)], jitter=0.0)
-    assert int(info[0]) > 0                                  # LAPACK-style: first failing leading minor
+    Ws, info = whiten([(Z, ls, -os_)], jitter=0.0)
+    assert int(info[0]) == 1                                 # LAPACK-style: first failing leading minor
     with settings.check_variational_cholesky(True):
         with pytest.raises(NotPSDError, match='not positive definite'):
-            whiten([(Z, ls, os_)], jitter=0.0)
-        Ws, info = whiten([(Z, ls, os_)], jitter=1e-4)       # the default jitter repairs it
+            whiten([(Z, ls, -os_)], jitter=0.0)
+        Ws, info = whiten([(Z, ls, os_)], jitter=1e-4)       # duplicate points: the default jitter repairs them
         assert int(info[0]) == 0
