@@ -275,6 +275,7 @@ def main():
     from nsgp import ops
     from nsgp.dist import DataParallel, PhiloxEps, dp_objective, shard_bounds
     from nsgp.gp import settings
+    from nsgp.gp.module import transform_cache
 
     x_all, y_all = synthetic_grid()
     gperm = torch.Generator().manual_seed(SEED)
@@ -301,8 +302,9 @@ def main():
     def fwd_bwd():
         eps.start_step(0, row0=lo)
         opt.zero_grad()
-        out = model(x_in)
-        loss = dp_objective(mll, out, y_in, gbatch, world * share, negate=True)        # = -(rank's share of the ELBO)
+        with transform_cache():                  # the likelihood's noise shares the model's packed softplus launch
+            out = model(x_in)
+            loss = dp_objective(mll, out, y_in, gbatch, world * share, negate=True)    # = -(rank's share of the ELBO)
         loss.backward()
         opt.bucket.gather_grads()            # one multi-tensor copy into the flat gradient bucket
         return loss.detach()

@@ -8,7 +8,7 @@ from . import settings
 from .distributions import MultivariateNormal, MultitaskMultivariateNormal
 from .lazy import delazify
 from .likelihoods import GaussianLikelihood
-from .module import Module, transform_cache
+from .module import Module, prefill_softplus_transforms, transform_cache
 
 
 class GP(Module):
@@ -189,6 +189,8 @@ class DeepGP(GP):
                       if hasattr(s, 'whiten_group')]
         shared = False
         with transform_cache():
+            if args and torch.is_tensor(args[0]) and args[0].is_cuda:
+                prefill_softplus_transforms(self)         # all raw hyper-parameters in one softplus launch
             if len(strategies) > 1 and len({s.inducing_points.shape[-2] for s in strategies}) == 1 \
                     and args and torch.is_tensor(args[0]) and args[0].is_cuda:
                 for s in strategies:

@@ -15,6 +15,7 @@ from .constraints import Interval
 # per (parameter, version) instead of once per property access (a DSVI step reads each lengthscale /
 # outputscale three times).  The scope ends with the forward pass, so no autograd graph outlives its backward.
 _transform_cache = []
+_lower_bound_vectors = {}
 
 
 class transform_cache:
@@ -25,6 +26,75 @@ class transform_cache:
     def __exit__(self, *exc):
         _transform_cache.pop()
         return False
+
+
+class _SplitPackedFn(torch.autograd.Function):
+    """packed:(n,) -> views of it in the given shapes; the backward is ONE cat of the incoming gradients."""
+
+    @staticmethod
+    def forward(ctx, packed, *shapes):
+        ctx.shapes = shapes
+        outs, off = [], 0
+        for shp in shapes:
+            n = 1
+            for d in shp:
+                n *= d
+            outs.append(packed[off:off + n].view(shp))
+            off += n
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        parts = []
+        for g, shp in zip(grads, ctx.shapes):
+            if g is None:
+                n = 1
+                for d in shp:
+                    n *= d
+                parts.append(None if n == 0 else n)
+            else:
+                parts.append(g.reshape(-1))
+        ref = next(p for p in parts if torch.is_tensor(p))
+        parts = [p if torch.is_tensor(p) else ref.new_zeros(p) for p in parts if p is not None]
+        return (torch.cat(parts), *([None] * len(ctx.shapes)))
+
+
+def prefill_softplus_transforms(root):
+    """Inside a `transform_cache()` scope: compute softplus(raw) for EVERY softplus-constrained CUDA parameter under
+    `root` with one cat + one softplus (and one add where a lower bound is non-zero) instead of a launch per parameter,
+    and seed the cache with views of the result; the backward is one cat + one softplus_backward.  (A DSVI step of
+    models/dgps.py has five such parameters: two lengthscales, two output scales, the noise.)"""
+    import math
+    if not _transform_cache:
+        return
+    cache = _transform_cache[-1]
+    todo, seen = [], set()
+    for mod in root.modules():
+        cons = getattr(mod, '_constraints', None)
+        if not cons:
+            continue
+        for cname, c in cons.items():
+            p = mod._parameters.get(cname[:-len('_constraint')])
+            if p is None or id(p) in seen or not p.is_cuda or type(c).transform is not Interval.transform \
+                    or not math.isinf(float(c.upper_bound)) or p.numel() == 0:
+                continue
+            key = (id(p), p._version, torch.is_grad_enabled())
+            if key in cache:
+                continue
+            seen.add(id(p))
+            todo.append((key, p, float(c.lower_bound)))
+    if len(todo) < 2 or len({(t[1].dtype, t[1].device) for t in todo}) != 1:
+        return
+    sp = torch.nn.functional.softplus(torch.cat([p.reshape(-1) for _, p, _ in todo]))
+    if any(lb != 0.0 for _, _, lb in todo):
+        k = (tuple((id(p), p.numel(), lb) for _, p, lb in todo), sp.dtype, sp.device)
+        vec = _lower_bound_vectors.get(k)
+        if vec is None:                                   # built once (before any graph capture), then resident
+            vec = _lower_bound_vectors[k] = torch.cat(
+                [torch.full((p.numel(),), lb, dtype=sp.dtype) for _, p, lb in todo]).to(sp.device)
+        sp = sp + vec
+    for (key, _, _), val in zip(todo, _SplitPackedFn.apply(sp, *[tuple(p.shape) for _, p, _ in todo])):
+        cache[key] = val
 
 
 class Module(nn.Module):
