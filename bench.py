@@ -299,13 +299,15 @@ def main():
     # static minibatch buffers: a step always reads these (hipGraph replays need fixed addresses)
     x_in, y_in = torch.empty_like(xs[0]), torch.empty_like(ys[0])
 
+    one = torch.ones((), device=device)
+
     def fwd_bwd():
         eps.start_step(0, row0=lo)
         opt.zero_grad()
         with transform_cache():                  # the likelihood's noise shares the model's packed softplus launch
             out = model(x_in)
             loss = dp_objective(mll, out, y_in, gbatch, world * share, negate=True)    # = -(rank's share of the ELBO)
-        loss.backward()
+        loss.backward(gradient=one)          # resident seed: no ones_like fill launch per step
         opt.bucket.gather_grads()            # one multi-tensor copy into the flat gradient bucket
         return loss.detach()
 

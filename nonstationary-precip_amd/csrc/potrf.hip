@@ -323,7 +323,11 @@ __device__ __forceinline__ void panel_body(unsigned char* panel_smem, T* __restr
         T* dst = wsL + (b * npanels + pj) * NB * NB;
 #pragma unroll
         for (int i = 0; i < SB; ++i) dst[(w * SB + i) * NB + lane] = S[(w * SB + i) * LDD + lane];
-        if (tid == 0 && bad && info[b] == 0) info[b] = (int32_t)(j0 + bad);
+        // the first panel initialises info (no memset launch); later panels record only the first failure
+        if (tid == 0) {
+            if (j0 == 0) info[b] = bad ? (int32_t)bad : 0;
+            else if (bad && info[b] == 0) info[b] = (int32_t)(j0 + bad);
+        }
     }
     if (rows == 0) return;                               // workgroup-uniform
 
@@ -481,7 +485,10 @@ __global__ __launch_bounds__(64) void potrf_tail_kernel(T* __restrict__ A, int64
     T* dst = wsL + (b * npanels + pj) * NB * NB;
     if (lane < nb)
         for (int j = 0; j <= lane; ++j) dst[lane * NB + j] = Ls[lane * LDD + j];
-    if (lane == 0 && bad && info[b] == 0) info[b] = (int32_t)(j0 + bad);
+    if (lane == 0) {
+        if (j0 == 0) info[b] = bad ? (int32_t)bad : 0;
+        else if (bad && info[b] == 0) info[b] = (int32_t)(j0 + bad);
+    }
 }
 
 // Finalisation: one workgroup per 64x64 tile on or above the diagonal.  Diagonal tiles receive their factor
@@ -516,8 +523,6 @@ int potrf_impl(T* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int32_t*
     if (batch > 65535) return -5;
     T* wsL = (T*)ws;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(info, 0, sizeof(int32_t) * batch, st);
-    if (e != hipSuccess) return (int)e;
     const size_t step_lds = (4 * (size_t)NB * LDD + 4 * SB * LDI + NB) * sizeof(T);
     static bool attr_set = false;       // idempotent attribute, set once per process and type
     if (!attr_set) {

@@ -197,7 +197,7 @@ class DeepGP(GP):
                     s._maybe_init()
                 groups = [s.whiten_group() for s in strategies]
                 Ws, _info, passed = whiten(groups, settings.variational_cholesky_jitter.value(args[0].dtype),
-                                           settings.chol_bwd_f64.on(), passthrough=True)
+                                           settings.chol_bwd_f64.on(), passthrough=True, out_dtype=args[0].dtype)
                 for s, W, zlo in zip(strategies, Ws, passed):
                     s._W64_shared = W
                     s._kernel_params_shared = zlo            # (Z, ls, os) routed through the whitening node

@@ -355,7 +355,7 @@ def potrf(A, check=False, overwrite=False):
     L = A if (overwrite and A.is_contiguous()) else A.contiguous().clone()
     n = L.shape[-1]
     batch = L.shape[0] if L.dim() == 3 else 1
-    info = torch.zeros(batch, dtype=torch.int32, device=ref.device)
+    info = (torch.empty if n > 0 else torch.zeros)(batch, dtype=torch.int32, device=ref.device)   # set by the first panel
     lib = _lib.load()
     ws = _ws(lib.nsgp_potrf_workspace(n, batch, ref.element_size()), ref.device)
     _lib.call(f'nsgp_potrf_{_sfx(ref)}', _p(L), n, n, n * n, batch, _p(info), _p(ws), ws.numel(), _stream())

@@ -38,7 +38,7 @@ class WhitenFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, jitter, chol_bwd_f64, *params):
+    def forward(ctx, jitter, chol_bwd_f64, out_dtype, *params):
         groups = [params[i:i + 3] for i in range(0, len(params), 3)]
         z64, off = [], 0
         M = groups[0][0].shape[-2]
@@ -62,9 +62,11 @@ class WhitenFn(torch.autograd.Function):
         ctx.dtypes = [g[0].dtype for g in groups]
         ctx.chol_bwd_f64 = chol_bwd_f64
         ctx.mark_non_differentiable(info)
+        # the layers consume W in their own dtype: ONE cast of the batched result here instead of one per layer
+        Wout = W64 if out_dtype in (None, torch.float64) else ops.cast(W64, out_dtype)
         outs, off = [], 0
         for b in ctx.sizes:                      # one output per group (views of the batched result)
-            outs.append(W64[off:off + b])
+            outs.append(Wout[off:off + b])
             off += b
         return (*outs, info, *[t.view_as(t) for t in flat])
 
@@ -73,11 +75,20 @@ class WhitenFn(torch.autograd.Function):
         W64, *flat = ctx.saved_tensors
         ng = len(ctx.sizes)
         gpass = gouts[ng + 1:]                               # gradients that came in through the pass-throughs
-        parts = []
-        for gi, b in enumerate(ctx.sizes):
-            g = gouts[gi]
-            parts.append(g if g is not None else torch.zeros((b, *W64.shape[1:]), dtype=W64.dtype, device=W64.device))
-        Wbar = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
+        if ng == 1 and gouts[0] is not None and gouts[0].dtype == W64.dtype:
+            Wbar = gouts[0]
+        else:                                    # float64 batched Wbar: cast + placement in one multi-tensor copy
+            Wbar = torch.empty_like(W64)
+            dst, src, off = [], [], 0
+            for gi, b in enumerate(ctx.sizes):
+                if gouts[gi] is None:
+                    Wbar[off:off + b].zero_()
+                else:
+                    dst.append(Wbar[off:off + b])
+                    src.append(gouts[gi])
+                off += b
+            if dst:
+                torch._foreach_copy_(dst, src)
         if ctx.chol_bwd_f64:
             Wb, Wc = Wbar.contiguous(), W64
         else:
@@ -107,14 +118,15 @@ class WhitenFn(torch.autograd.Function):
         extra = [(o, g) for o, g in zip(outs, gpass) if g is not None]
         if extra:
             torch._foreach_add_([o for o, _ in extra], [g.reshape(o.shape) for o, g in extra])
-        return (None, None, *outs)
+        return (None, None, None, *outs)
 
 
-def whiten(groups, jitter=1e-4, chol_bwd_f64=True, passthrough=False):
-    """groups: list of (Z:(b,M,D), ls:(b,D), os:(b,)).  Returns (list of W64:(b,M,M) per group, info); with
+def whiten(groups, jitter=1e-4, chol_bwd_f64=True, passthrough=False, out_dtype=None):
+    """groups: list of (Z:(b,M,D), ls:(b,D), os:(b,)).  Returns (list of W:(b,M,M) per group -- float64 unless
+    `out_dtype` asks for the layers' dtype --, info); with
     passthrough=True also the list of (Z, ls, os) pass-through triples a layer should build its Kzx from (WhitenFn)."""
     flat = [t for g in groups for t in g]
-    res = WhitenFn.apply(float(jitter), bool(chol_bwd_f64), *flat)
+    res = WhitenFn.apply(float(jitter), bool(chol_bwd_f64), out_dtype, *flat)
     ng = len(groups)
     Ws, info, rest = res[:ng], res[ng], res[ng + 1:]
     from .gp import settings
@@ -135,7 +147,7 @@ class SVGPLayerFn(torch.autograd.Function):
 
     x:(n,D) shared by the b output GPs, or (b,n,D);  Z:(b,M,D)  ls:(b,D)  os:(b,)  m:(b,M)  Lq:(b,M,M)
     (only the lower triangle of Lq is used, like CholeskyVariationalDistribution.forward);
-    W64:(b,M,M) = chol(Kzz)^-1 from WhitenFn (float64).  The dependence of Kzz on (Z, ls, os) flows
+    W64:(b,M,M) = chol(Kzz)^-1 from WhitenFn (float64, or already in x's dtype).  The dependence of Kzz on (Z, ls, os) flows
     through W64's gradient; this node differentiates the Kzx path.
     mean_w:(D,) or (b,D) and mean_c:(1,) or (b,) are the weights / constant of an affine prior mean function
     (gpytorch LinearMean / ConstantMean, models/dgps.py:40-43); either may be None.  The prior mean is added in the
@@ -145,7 +157,7 @@ class SVGPLayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, Z, ls, os_, m, Lq, W64, mean_w, mean_c):
-        W = ops.cast(W64, x.dtype)
+        W = W64 if W64.dtype == x.dtype else ops.cast(W64, x.dtype)
         Kzx = ops.rbf_build(Z, x, ls, os_)                                       # (b,M,n)
         affine = None if (mean_w is None and mean_c is None) else (x, mean_w, mean_c)
         A, C, mean, var = ops.svgp_project(W, Kzx, Lq, m, os_, base_add=VAR_JITTER, affine=affine)   # 2 GEMMs
@@ -171,7 +183,7 @@ class SVGPLayerFn(torch.autograd.Function):
             if x.dim() == 2:
                 gx = gx[0] if gx.shape[0] == 1 else gx.sum(0)
         return (gx if need_x else None, gZ, gls.reshape(ls.shape), gos.reshape(os_.shape), mbar, Lqbar,
-                ops.cast(Wbar, ctx.w_dtype),
+                Wbar if Wbar.dtype == ctx.w_dtype else ops.cast(Wbar, ctx.w_dtype),
                 None if mean_w is None else wbar.reshape(mean_w.shape),
                 None if mean_c is None else cbar.reshape(mean_c.shape))
 
@@ -182,6 +194,7 @@ def svgp_marginal(x, Z, ls, os_, m, Lq, jitter=1e-4, chol_bwd_f64=True, W64=None
     Returns (mean, var, info); pass W64 (from `whiten`) to share one factorisation chain across layers."""
     info = None
     if W64 is None:
-        (W64,), info, ((Z, ls, os_),) = whiten([(Z, ls, os_)], jitter, chol_bwd_f64, passthrough=True)
+        (W64,), info, ((Z, ls, os_),) = whiten([(Z, ls, os_)], jitter, chol_bwd_f64, passthrough=True,
+                                               out_dtype=x.dtype)
     mean, var = SVGPLayerFn.apply(x, Z, ls, os_, m, Lq, W64, mean_w, mean_c)
     return mean, var, info
