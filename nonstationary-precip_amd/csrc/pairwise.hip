@@ -460,12 +460,10 @@ template <typename T> struct OutDesc {
 // item are `ntiles` strided loads; one serial chain of 160 dependent-latency loads took 40 us at n2 = 40960), combined
 // through LDS in a fixed order (deterministic).
 template <typename T>
-__global__ __launch_bounds__(256) void reduce_items_kernel(const T* __restrict__ P, int64_t ntiles, int64_t n,
-                                                           OutDesc<T> od) {
-    __shared__ T lds[8][33];
-    const int64_t b = blockIdx.z;
+__device__ __forceinline__ void reduce_items_body(const T* __restrict__ P, int64_t ntiles, int64_t n,
+                                                  const OutDesc<T>& od, int64_t blk, int64_t b, T (*lds)[33]) {
     const int ix = threadIdx.x & 31, cy = threadIdx.x >> 5;
-    const int64_t idx = (int64_t)blockIdx.x * 32 + ix;
+    const int64_t idx = blk * 32 + ix;
     const int64_t tot = n * od.nval;
     T s = T(0);
     if (idx < tot) {
@@ -484,18 +482,26 @@ __global__ __launch_bounds__(256) void reduce_items_kernel(const T* __restrict__
     od.ptr[k][b * od.bstride[k] + i * od.stride[k]] = s;
 }
 
-// global values: one block per (batch), sums `nparts` partials of `nval` values each
+// ONE launch for the three reductions behind a backward tile pass (workgroups [0, nblk1): row items, [nblk1, nblk1 +
+// nblk2): column items, the last one: the global values of this batch entry, summing `nparts` partials of `nval` values).
 template <typename T>
-__global__ __launch_bounds__(256) void reduce_globals_kernel(const T* __restrict__ PG, int64_t nparts, OutDesc<T> od) {
-    __shared__ T lds[4];
-    const int64_t b = blockIdx.x;
-    for (int k = 0; k < od.nval; ++k) {
+__global__ __launch_bounds__(256) void reduce_all_kernel(const T* __restrict__ P1, int64_t ntj, int64_t n1,
+                                                         OutDesc<T> rows, const T* __restrict__ P2, int64_t nti,
+                                                         int64_t n2, OutDesc<T> cols, const T* __restrict__ PG,
+                                                         int64_t nparts, OutDesc<T> globs, int64_t nblk1,
+                                                         int64_t nblk2) {
+    __shared__ T lds[8][33];
+    const int64_t b = blockIdx.z, blk = blockIdx.x;
+    if (blk < nblk1) { reduce_items_body<T>(P1, ntj, n1, rows, blk, b, lds); return; }
+    if (blk < nblk1 + nblk2) { reduce_items_body<T>(P2, nti, n2, cols, blk - nblk1, b, lds); return; }
+    T* l4 = &lds[0][0];
+    for (int k = 0; k < globs.nval; ++k) {
         T s = T(0);
-        for (int64_t t = threadIdx.x; t < nparts; t += 256) s += PG[(b * nparts + t) * od.nval + k];
-        s = block_sum_256(s, lds);
-        if (threadIdx.x == 0 && od.ptr[k]) {
-            if (od.div[k]) s /= od.div[k][b * od.divstride[k] + od.divoff[k]];
-            od.ptr[k][b * od.bstride[k]] = s;
+        for (int64_t t = threadIdx.x; t < nparts; t += 256) s += PG[(b * nparts + t) * globs.nval + k];
+        s = block_sum_256(s, l4);
+        if (threadIdx.x == 0 && globs.ptr[k]) {
+            if (globs.div[k]) s /= globs.div[k][b * globs.divstride[k] + globs.divoff[k]];
+            globs.ptr[k][b * globs.bstride[k]] = s;
         }
         __syncthreads();
     }
@@ -524,13 +530,10 @@ int launch_bwd(const Op& op, int64_t batch, int64_t n1, int64_t n2, const T* G, 
     else
         hipLaunchKernelGGL((pairwise_bwd_kernel<T, Op, BWD_TI>), dim3((unsigned)ntj, (unsigned)nti, (unsigned)batch),
                            dim3(256), 0, st, op, n1, n2, G, ldg, sG, P1, P2, PG);
-    hipLaunchKernelGGL((reduce_items_kernel<T>), dim3((unsigned)cdiv64(n1 * Op::NR, 32), 1, (unsigned)batch),
-                       dim3(256), 0, st, (const T*)P1, ntj, n1, rows);
-    hipLaunchKernelGGL((reduce_items_kernel<T>), dim3((unsigned)cdiv64(n2 * Op::NC, 32), 1, (unsigned)batch),
-                       dim3(256), 0, st, (const T*)P2, nti, n2, cols);
-    if (globs.nval > 0)
-        hipLaunchKernelGGL((reduce_globals_kernel<T>), dim3((unsigned)batch), dim3(256), 0, st, (const T*)PG,
-                           nti * ntj, globs);
+    const int64_t nblk1 = cdiv64(n1 * Op::NR, 32), nblk2 = cdiv64(n2 * Op::NC, 32);
+    hipLaunchKernelGGL((reduce_all_kernel<T>), dim3((unsigned)(nblk1 + nblk2 + (globs.nval > 0 ? 1 : 0)), 1, (unsigned)batch),
+                       dim3(256), 0, st, (const T*)P1, ntj, n1, rows, (const T*)P2, nti, n2, cols, (const T*)PG,
+                       nti * ntj, globs, nblk1, nblk2);
     return nsgp_launch_status();
 }
 
