@@ -73,7 +73,8 @@ int nsgp_rbf_build_fwd_f32(const float* x1, const float* x2, const float* ls, co
 int nsgp_rbf_build_fwd_f64(const double* x1, const double* x2, const double* ls, const double* os,
                            int64_t batch, int64_t n1, int64_t n2, int D, int64_t sx1, int64_t sx2,
                            double diag_add, double* K, int64_t ldk, int64_t sK, void* stream);
-/* backward: outputs (any may be NULL) g_x1:(batch,n1,D) g_x2:(batch,n2,D) g_ls:(batch,D) g_os:(batch) */
+/* backward: outputs (any may be NULL) g_x1:(batch,n1,D) g_x2:(batch,n2,D) g_ls:(batch,D) g_os:(batch).
+ * g_x1 == g_x2 (one buffer, n1 == n2): the row- and column-side gradients are SUMMED into it -- the x1 = x2 (Kzz) case. */
 size_t nsgp_rbf_build_bwd_workspace(int64_t batch, int64_t n1, int64_t n2, int D, int elem_size);
 int nsgp_rbf_build_bwd_f32(const float* x1, const float* x2, const float* ls, const float* os,
                            int64_t batch, int64_t n1, int64_t n2, int D, int64_t sx1, int64_t sx2,

@@ -461,7 +461,8 @@ template <typename T> struct OutDesc {
 // through LDS in a fixed order (deterministic).
 template <typename T>
 __device__ __forceinline__ void reduce_items_body(const T* __restrict__ P, int64_t ntiles, int64_t n,
-                                                  const OutDesc<T>& od, int64_t blk, int64_t b, T (*lds)[33]) {
+                                                  const OutDesc<T>& od, int64_t blk, int64_t b, T (*lds)[33],
+                                                  const T* __restrict__ Pb = nullptr, int64_t ntb = 0) {
     const int ix = threadIdx.x & 31, cy = threadIdx.x >> 5;
     const int64_t idx = blk * 32 + ix;
     const int64_t tot = n * od.nval;
@@ -469,6 +470,10 @@ __device__ __forceinline__ void reduce_items_body(const T* __restrict__ P, int64
     if (idx < tot) {
         const T* p = P + b * ntiles * tot + idx;
         for (int64_t t = cy; t < ntiles; t += 8) s += p[t * tot];
+        if (Pb) {                                         // symmetric case: the other side's partials of the same item
+            const T* q = Pb + b * ntb * tot + idx;
+            for (int64_t t = cy; t < ntb; t += 8) s += q[t * tot];
+        }
     }
     lds[cy][ix] = s;
     __syncthreads();
@@ -492,7 +497,7 @@ __global__ __launch_bounds__(256) void reduce_all_kernel(const T* __restrict__ P
                                                          int64_t nblk2) {
     __shared__ T lds[8][33];
     const int64_t b = blockIdx.z, blk = blockIdx.x;
-    if (blk < nblk1) { reduce_items_body<T>(P1, ntj, n1, rows, blk, b, lds); return; }
+    if (blk < nblk1) { reduce_items_body<T>(P1, ntj, n1, rows, blk, b, lds, nblk2 == 0 ? P2 : nullptr, nti); return; }
     if (blk < nblk1 + nblk2) { reduce_items_body<T>(P2, nti, n2, cols, blk - nblk1, b, lds); return; }
     T* l4 = &lds[0][0];
     for (int k = 0; k < globs.nval; ++k) {
@@ -530,10 +535,19 @@ int launch_bwd(const Op& op, int64_t batch, int64_t n1, int64_t n2, const T* G, 
     else
         hipLaunchKernelGGL((pairwise_bwd_kernel<T, Op, BWD_TI>), dim3((unsigned)ntj, (unsigned)nti, (unsigned)batch),
                            dim3(256), 0, st, op, n1, n2, G, ldg, sG, P1, P2, PG);
-    const int64_t nblk1 = cdiv64(n1 * Op::NR, 32), nblk2 = cdiv64(n2 * Op::NC, 32);
+    // x1 == x2 with ONE gradient buffer for both sides (rows and cols describe the same outputs): the row-side blocks
+    // add the column-side partials of their item and no column-side blocks run
+    bool sym = n1 == n2 && Op::NR == Op::NC;
+    bool any = false;
+    for (int k = 0; sym && k < Op::NR; ++k) {
+        sym = rows.ptr[k] == cols.ptr[k] && rows.stride[k] == cols.stride[k] && rows.bstride[k] == cols.bstride[k];
+        any = any || rows.ptr[k] != nullptr;
+    }
+    sym = sym && any;
+    const int64_t nblk1 = cdiv64(n1 * Op::NR, 32), nblk2 = sym ? 0 : cdiv64(n2 * Op::NC, 32);
     hipLaunchKernelGGL((reduce_all_kernel<T>), dim3((unsigned)(nblk1 + nblk2 + (globs.nval > 0 ? 1 : 0)), 1, (unsigned)batch),
-                       dim3(256), 0, st, (const T*)P1, ntj, n1, rows, (const T*)P2, nti, n2, cols, (const T*)PG,
-                       nti * ntj, globs, nblk1, nblk2);
+                       dim3(256), 0, st, (const T*)P1, ntj, n1, rows, (const T*)(sym || nblk2 ? P2 : nullptr), nti, n2, cols,
+                       (const T*)PG, nti * ntj, globs, nblk1, nblk2);
     return nsgp_launch_status();
 }
 

@@ -160,13 +160,19 @@ def rbf_build(x1, x2, ls, os_, diag_add=0.0, out=None):
     return K
 
 
-def rbf_build_bwd(x1, x2, ls, os_, G, need_x1=True, need_x2=True):
-    """Returns g_x1:(batch,n1,D) g_x2:(batch,n2,D) (per-batch, caller sums if x was shared) g_ls, g_os."""
+def rbf_build_bwd(x1, x2, ls, os_, G, need_x1=True, need_x2=True, sym=False):
+    """Returns g_x1:(batch,n1,D) g_x2:(batch,n2,D) (per-batch, caller sums if x was shared) g_ls, g_os.
+    sym=True (x1 is x2, the Kzz case): ONE buffer receives the sum of the row- and column-side gradients and is
+    returned for both."""
     ref, x1, x2, ls, os_, batch, n1, n2, D, sx1, sx2 = _rbf_args(x1, x2, ls, os_)
     _chk(ref, G)
     G = _c(G).reshape(batch, n1, n2)
     g_x1 = torch.empty((batch, n1, D), dtype=ref.dtype, device=ref.device) if need_x1 else None
     g_x2 = torch.empty((batch, n2, D), dtype=ref.dtype, device=ref.device) if need_x2 else None
+    if sym:
+        if n1 != n2 or sx1 != sx2 or not (need_x1 and need_x2):
+            raise BackendError('rbf_build_bwd: sym needs x1 and x2 of one shape and both gradients')
+        g_x2 = g_x1
     g_ls = torch.empty((batch, D), dtype=ref.dtype, device=ref.device)
     g_os = torch.empty((batch,), dtype=ref.dtype, device=ref.device)
     lib = _lib.load()

@@ -62,6 +62,7 @@ class WhitenFn(torch.autograd.Function):
         ctx.dtypes = [g[0].dtype for g in groups]
         ctx.chol_bwd_f64 = chol_bwd_f64
         ctx.mark_non_differentiable(info)
+        ctx.set_materialize_grads(False)         # no zero-fill launches for outputs nobody differentiated
         # the layers consume W in their own dtype: ONE cast of the batched result here instead of one per layer
         Wout = W64 if out_dtype in (None, torch.float64) else ops.cast(W64, out_dtype)
         outs, off = [], 0
@@ -106,8 +107,8 @@ class WhitenFn(torch.autograd.Function):
                 Zk, lsk, osk = Zd.float(), lsd.float(), osd.float()
             else:
                 Zk, lsk, osk = Zd, lsd, osd
-            gZa, gZb, gls, gos = ops.rbf_build_bwd(Zk, Zk, lsk, osk, Kb.contiguous())
-            grads += [gZa.add_(gZb), gls, gos]
+            gZ, _, gls, gos = ops.rbf_build_bwd(Zk, Zk, lsk, osk, Kb.contiguous(), sym=True)   # both sides summed
+            grads += [gZ, gls, gos]
         # back to the parameters' dtypes with ONE multi-tensor copy
         outs = [g if g.dtype == ctx.dtypes[i // 3] else torch.empty(g.shape, dtype=ctx.dtypes[i // 3], device=g.device)
                 for i, g in enumerate(grads[2:])]

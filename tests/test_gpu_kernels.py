@@ -441,6 +441,24 @@ def test_fused_adam_matches_oracle(ops):
     assert torch.allclose(p.cpu().double(), mine[0], rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize('dt', [F64, F32])
+@pytest.mark.parametrize('b,n,D', [(1, 70, 2), (3, 257, 3), (2, 1024, 2)])
+def test_rbf_backward_symmetric_mode_sums_both_sides(ops, dt, b, n, D):
+    """rbf_build_bwd(x, x, sym=True): one gradient buffer for both arguments receives g_x1 + g_x2 (the Kzz case of the
+    whitening chain), the other outputs are unchanged -- against the two-buffer call on the same (non-symmetric) G."""
+    g = torch.Generator().manual_seed(11 + n)
+    x = torch.randn(b, n, D, generator=g, dtype=F64).to(dt).cuda()
+    ls = (torch.rand(b, D, generator=g, dtype=F64) + 0.5).to(dt).cuda()
+    os_ = (torch.rand(b, generator=g, dtype=F64) + 0.5).to(dt).cuda()
+    G = torch.randn(b, n, n, generator=g, dtype=F64).to(dt).cuda()
+    g1, g2, gls, gos = ops.rbf_build_bwd(x, x, ls, os_, G)
+    s1, s2, sls, sos = ops.rbf_build_bwd(x, x, ls, os_, G, sym=True)
+    assert s1 is s2
+    tol = dict(rtol=1e-11, atol=1e-11) if dt == F64 else dict(rtol=2e-5, atol=2e-5)
+    assert torch.allclose(s1, g1 + g2, **tol)
+    assert torch.equal(sls, gls) and torch.equal(sos, gos)
+
+
 def test_cpu_tensors_are_rejected_loudly(ops):
     from nsgp import BackendError
     x = torch.randn(4, 2)
