@@ -1,4 +1,4 @@
 import json,sys
 for l in sys.stdin:
     if l.startswith('{"metric"'):
-        d=json.loads(l); r=d['roofline']; print(d['value'], d['ms_per_step'], 'gemm_ms', r['gemm_ms_per_step'], 'TF', r['achieved'])
+        d=json.loads(l); r=d['roofline']; print(d['value'], d['ms_per_step'], 'gemm_ms', r['gemm_ms_per_step'], 'TF', r['achieved'], 'final_loss', d.get('final_loss'))
