@@ -74,10 +74,12 @@ __device__ __forceinline__ float fast_rsqrt(float a) {
     return r;
 }
 __device__ __forceinline__ double fast_rsqrt(double a) {
-    double r = __builtin_amdgcn_rsq(a);                      // ~2^-26 relative error
-    r = r * (1.5 - 0.5 * a * r * r);
-    r = r * (1.5 - 0.5 * a * r * r);
-    return r;
+    // v_rsq_f64 is good to 5.2e-8 (tools/probes/rsq_f64_accuracy.hip); ONE cubic step r (1 + e/2 + 3 e^2/8), e = 1 - a r^2,
+    // lands within 0.62 ulp with a dependent chain of 4 operations (two quadratic Newton steps: 8, 2.2 ulp) -- this sits
+    // on the serial pivot chain of every column
+    const double r = __builtin_amdgcn_rsq(a);
+    const double e = __builtin_fma(-(a * r), r, 1.0);
+    return __builtin_fma(r * e, __builtin_fma(e, 0.375, 0.5), r);
 }
 
 // Ragged tail (nb < 64): same algorithm with the block in LDS (lane i owns row i) and run-time loop
