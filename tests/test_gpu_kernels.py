@@ -78,6 +78,37 @@ def test_gibbs_bwd_matches_oracle_autograd(ops, dt, n1, n2, D):
     assert torch.allclose(os_c.grad.cpu().double(), os_.grad, **tol)
 
 
+@pytest.mark.parametrize('dt', [F64, F32])
+def test_gibbs_and_rbf_exponent_range(ops, dt):
+    """The build kernels' own exp (csrc/common.h) over the whole argument range: entries whose exponent runs from 0
+    through the float64 denormal range to far below it (-1e6) must agree with the oracle to its rounding, underflow to
+    (sub)normal zero without NaNs, and a NaN coordinate must stay a NaN in its row and column."""
+    from oracle import kernels as K
+    n, D = 96, 2
+    g = _g(21)
+    # points on a line with geometrically growing gaps: squared distances from 1e-6 to 1e6 lengthscales^2
+    t = torch.cat([torch.zeros(1, dtype=F64), torch.logspace(-3, 3, n - 1, dtype=F64)])
+    x = torch.stack([t, 0.5 * t], -1)
+    e = torch.exp(0.2 * torch.randn(D, n, generator=g, dtype=F64))
+    Kd = ops.gibbs_build(x.to(dt).cuda(), x.to(dt).cuda(), e.to(dt).cuda(), e.to(dt).cuda()).cpu().double()
+    ref = K.gibbs(x.to(dt).double(), x.to(dt).double(), e.to(dt).double(), e.to(dt).double())
+    assert torch.isfinite(Kd).all()
+    tol = dict(rtol=1e-11, atol=1e-300) if dt == F64 else dict(rtol=3e-5, atol=1e-37)
+    assert torch.allclose(Kd, ref, **tol)
+    assert float(Kd[0, -1]) == 0.0 or abs(float(Kd[0, -1])) < 1e-300        # exponent ~ -1e6: underflow, not NaN
+    ls = torch.ones(1, D, dtype=F64)
+    os_ = torch.ones(1, dtype=F64)
+    Kr = ops.rbf_build(x.to(dt).cuda().unsqueeze(0), x.to(dt).cuda().unsqueeze(0), ls.to(dt).cuda(), os_.to(dt).cuda())
+    refr = torch.exp(-0.5 * ((x.to(dt).double()[:, None, :] - x.to(dt).double()[None, :, :]) ** 2).sum(-1))
+    assert torch.allclose(Kr.cpu().double()[0], refr, **tol)
+    xn = x.clone()
+    xn[7, 0] = float('nan')
+    Kn = ops.gibbs_build(xn.to(dt).cuda(), xn.to(dt).cuda(), e.to(dt).cuda(), e.to(dt).cuda()).cpu()
+    assert torch.isnan(Kn[7]).all() and torch.isnan(Kn[:, 7]).all()
+    keep = [i for i in range(n) if i != 7]
+    assert torch.isfinite(Kn[keep][:, keep]).all()
+
+
 def test_gibbs_symmetric_roles_sum(ops):
     """K_xx with ell1 is ell2 (training path, models/gibbs_kernels.py:148-149): autograd adds both roles."""
     from oracle import kernels as K
