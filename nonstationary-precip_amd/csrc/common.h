@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <mutex>
+#include <unordered_set>
 #include "../../include/nsgp.h"
 
 #define NSGP_WAVE 64
@@ -10,6 +12,21 @@
 static inline int nsgp_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
+}
+
+// Opt a kernel in to more than 64 KB of dynamic LDS.  The attribute is per (kernel, device): keyed by hipGetDevice()
+// so that a second GPU in the same process gets it too, and guarded by a mutex because launches also come from
+// autograd's backward thread.
+static inline void nsgp_opt_in_lds(const void* kern, size_t lds) {
+    if (lds <= 65536) return;
+    static std::mutex mu;
+    static std::unordered_set<uint64_t> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t key = (uint64_t)(uintptr_t)kern * 64u + (uint64_t)(dev & 63);
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.insert(key).second)
+        (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

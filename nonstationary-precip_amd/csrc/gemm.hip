@@ -627,11 +627,7 @@ int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam,
         constexpr int pb = (MB == 0 && sizeof(T) == 4) ? 1 : Mfma<T>::PAD;                                \
         constexpr size_t lds = 2 * BKc * ((BM_ + pa) + (BN_ + pb)) * sizeof(T);                           \
         auto kern = gemm_kernel<T, BM_, BN_, BKc, MA, MB, EP, KS>;                                        \
-        static bool attr_done = false;                                                                    \
-        if (!attr_done && lds > 65536) {                                                                  \
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        }                                                                                                 \
-        attr_done = true;                                                                                 \
+        nsgp_opt_in_lds((const void*)kern, lds);                                                          \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g, alpha, A, B, beta, C, slabs, ep);           \
     } while (0)
 #define NSGP_LAUNCH_EPI(BMN)                                                                              \
@@ -673,11 +669,7 @@ int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam,
             break;                                                                                        \
         }                                                                                                 \
         auto kern = gemm_kernel<T, BMN, BMN, BKc, MA, MB>;                                                \
-        static bool attr_done = false;                                                                    \
-        if (!attr_done && lds > 65536) {                                                                  \
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        }                                                                                                 \
-        attr_done = true;                                                                                 \
+        nsgp_opt_in_lds((const void*)kern, lds);                                                          \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g, alpha, A, B, beta, C, slabs, ep);           \
     } while (0)
 #define NSGP_LAUNCH_MODES(BMN)                                                 \

@@ -526,13 +526,7 @@ int potrf_impl(T* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int32_t*
     T* wsL = (T*)ws;
     hipStream_t st = (hipStream_t)stream;
     const size_t step_lds = (4 * (size_t)NB * LDD + 4 * SB * LDI + NB) * sizeof(T);
-    static bool attr_set = false;       // idempotent attribute, set once per process and type
-    if (!attr_set) {
-        if (step_lds > 65536)
-            (void)hipFuncSetAttribute((const void*)potrf_step_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)step_lds);
-        attr_set = true;
-    }
+    nsgp_opt_in_lds((const void*)potrf_step_kernel<T>, step_lds);
     // Two-level blocking for large matrices: rank-64 updates stay inside a 256-column outer panel (they are
     // HBM-bound: 8 flop/B in float64), the rest of the trailing matrix is updated once per outer panel with
     // K = 256.  Small matrices (the DSVI Kzz, n ~ 1024) are latency-bound and use one level.
@@ -687,13 +681,7 @@ int trtri_impl(const T* L, int64_t n, int64_t ldl, int64_t sL, T* X, int64_t ldx
     if (batch > 65535) return -8;
     hipStream_t st = (hipStream_t)stream;
     const size_t diag_lds = (3 * (size_t)NB * LDD + 4 * SB * LDI + NB) * sizeof(T);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (diag_lds > 65536)
-            (void)hipFuncSetAttribute((const void*)trtri_diag_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)diag_lds);
-        attr_set = true;
-    }
+    nsgp_opt_in_lds((const void*)trtri_diag_kernel<T>, diag_lds);
     hipLaunchKernelGGL((trtri_diag_kernel<T>), dim3((unsigned)cdiv64(n, NB), (unsigned)batch), dim3(256), diag_lds, st,
                        L, n, ldl, sL, X, ldx, sX);
     T* Tm = (T*)ws;                      // (batch, n, n) scratch, same indexing as X with ld = n

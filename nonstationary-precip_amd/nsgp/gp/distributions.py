@@ -55,6 +55,28 @@ class MvnLogProbFn(torch.autograd.Function):
         return gK, gd
 
 
+def _checked_log_prob(lp, info, K, diff):
+    """psd_safe_cholesky's policy for the dense MVN log-density (gpytorch reaches it from MultivariateNormal.log_prob
+    -> lazy covariance Cholesky): a failed factorisation is retried with jitter 1e-6 * 10^i (float32) /
+    1e-8 * 10^i (float64), i < 3, under a NumericalWarning; then NotPSDError (NanError for NaN input) -- never a silent
+    NaN objective.  One host sync (reading `info`); the exact-GP loops sync on float(loss) every iteration anyway."""
+    if int(info.max().item()) == 0:
+        return lp
+    import warnings
+    from .utils.cholesky import NanError, NotPSDError, NumericalWarning
+    if torch.isnan(K).any():
+        raise NanError(f'cholesky: {int(torch.isnan(K).sum())} of {K.numel()} elements are NaN')
+    base = settings.cholesky_jitter.value(K.dtype)
+    eye = torch.eye(K.shape[-1], dtype=K.dtype, device=K.device)
+    for i in range(3):
+        jit = base * (10 ** i)
+        lp, info = MvnLogProbFn.apply(K + jit * eye, diff)
+        if int(info.max().item()) == 0:
+            warnings.warn(f'A not p.d., added jitter of {jit:.1e} to the diagonal', NumericalWarning)
+            return lp
+    raise NotPSDError(f'Matrix not positive definite after repeatedly adding jitter up to {jit:.1e}.')
+
+
 def _lowrank_diag_log_prob(root, diag, d):
     """log N(d | 0, R R^T + diag(D)) via the k x k Woodbury system (R:(n,k))."""
     n, k = root.shape[-2], root.shape[-1]
@@ -128,7 +150,9 @@ class MultivariateNormal:
                 and cov._lazy_tensor.root.shape[-1] < cov.shape[-1] and diff.dim() == 1:
             return _lowrank_diag_log_prob(cov._lazy_tensor.root.evaluate(), cov._diag_tensor.diag(), diff)
         K = cov.evaluate() if isinstance(cov, LazyTensor) else cov
-        lp, _ = MvnLogProbFn.apply(K, diff)
+        lp, info = MvnLogProbFn.apply(K, diff)
+        if settings.check_mvn_cholesky.on() and not torch.cuda.is_current_stream_capturing():
+            lp = _checked_log_prob(lp, info, K, diff)
         return lp
 
     def rsample(self, sample_shape=torch.Size(), base_samples=None):

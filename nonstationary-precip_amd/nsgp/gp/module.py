@@ -18,6 +18,12 @@ _transform_cache = []
 _lower_bound_vectors = {}
 
 
+def transform_cache_active():
+    """True inside a `transform_cache()` scope.  The cache keys on parameter versions, which the raw-pointer Adam
+    kernel (nsgp_adam_step_f32) never bumps: a scope must not span an optimiser step (FusedAdam.step checks)."""
+    return bool(_transform_cache)
+
+
 class transform_cache:
     def __enter__(self):
         _transform_cache.append(_transform_cache[-1] if _transform_cache else {})   # nested scopes share

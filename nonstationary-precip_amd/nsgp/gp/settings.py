@@ -115,6 +115,13 @@ class chol_bwd_f64(_feature_flag):
     _state = True
 
 
+class check_mvn_cholesky(_feature_flag):
+    """On (default): MultivariateNormal.log_prob reads the Cholesky `info` of its dense covariance (one host sync) and
+    follows psd_safe_cholesky -- jitter retries with a NumericalWarning, then NotPSDError -- instead of returning a NaN
+    objective.  Off: sync-free (for graph capture of an exact-GP step; skipped automatically while a stream captures)."""
+    _state = True
+
+
 class check_variational_cholesky(_feature_flag):
     """Off (default): the DSVI step never synchronises with the host -- a Kzz that is not positive definite shows up as
     NaNs in the ELBO (gpytorch would have raised from psd_safe_cholesky after its jitter retries).  On: read the

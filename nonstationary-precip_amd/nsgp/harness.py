@@ -82,6 +82,11 @@ def fit(model, loss_fn, optimizer, max_iters=1000, threshold=1e-6, logdir=None, 
             old = loss_val
             loss = loss_fn()
             loss_val = float(loss.detach())
+            if not math.isfinite(loss_val):
+                # a NaN/inf objective never satisfies |change| < threshold: without this check the loop would keep
+                # stepping on NaN gradients until max_iters and checkpoint NaN parameters
+                raise FloatingPointError(f'objective is {loss_val} at iteration {i}: stopping before the optimiser '
+                                         'step (last finite parameters are in best.tar when logdir is set)')
             change = abs(old - loss_val)
             loss.backward()
             if i % max(1, int(log_interval)) == 0:

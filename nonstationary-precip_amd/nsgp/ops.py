@@ -51,6 +51,11 @@ def _chk(*ts):
         elif t.dtype != first.dtype or t.device != first.device:
             raise BackendError(f'mixed dtype/device: {t.dtype}/{t.device} vs {first.dtype}/{first.device}')
     _sfx(first)
+    if first.device.index != torch.cuda.current_device():
+        # every wrapper launches on torch.cuda.current_stream() of the CURRENT device: device-1 pointers on device 0's
+        # stream would be a GPU memory fault, not an error code
+        raise BackendError(f'tensors live on {first.device} but the current device is cuda:{torch.cuda.current_device()}: '
+                           'call torch.cuda.set_device(...) (one process per GPU) or wrap the call in torch.cuda.device(...)')
     return first
 
 

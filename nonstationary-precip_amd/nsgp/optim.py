@@ -58,8 +58,18 @@ class FlatBucket:
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + off * self.flat_g.element_size():
                 p.grad = self.flat_g[off:off + n].view(p.shape)
 
+    def check_homed(self):
+        """Raise if a parameter no longer lives in the flat buffer (model.to() / .double() / .cuda() after the bucket
+        was built re-allocates p.data: Adam would then update an orphan buffer).  Pointer compares only, no sync."""
+        base, es = self.flat_p.data_ptr(), self.flat_p.element_size()
+        for p, (off, n) in zip(self.params, self.offsets):
+            if p.data_ptr() != base + off * es or p.dtype != self.flat_p.dtype:
+                raise RuntimeError('FlatBucket: a parameter was moved out of the flat buffer (model.to()/.double()/'
+                                   '.cuda() after the optimiser was built?); rebuild the FlatBucket / FusedAdam')
+
     def gather_grads(self):
         """Pack the parameters' .grad tensors into the flat gradient buffer (no-op for view gradients)."""
+        self.check_homed()
         if self.grads_as_views:
             return
         dst, src, missing = [], [], []
@@ -89,12 +99,46 @@ class FusedAdam:
         self.steps = 0
         self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.bucket.flat_p.device) if capturable else None
 
+    @property
+    def param_groups(self):
+        """torch.optim-style view (read-only use: schedulers / logging read `lr`)."""
+        return [{'params': self.bucket.params, 'lr': self.lr, 'betas': self.betas, 'eps': self.eps}]
+
+    def state_dict(self):
+        """Plain tensors / numbers only, so harness checkpoints load with torch.load(weights_only=True)
+        (the reference's best.tar / final.tar carry 'optim_state', experiments/precipitation_baselines.py:376-397)."""
+        return {'step': int(self.steps), 'exp_avg': self.exp_avg.detach().clone(),
+                'exp_avg_sq': self.exp_avg_sq.detach().clone(), 'lr': float(self.lr),
+                'betas': [float(self.betas[0]), float(self.betas[1])], 'eps': float(self.eps),
+                'numel': int(self.bucket.numel)}
+
+    def load_state_dict(self, state):
+        """In-place restore: the moment buffers and the device step counter keep their addresses, so a hipGraph
+        captured around step() stays valid."""
+        if int(state['numel']) != self.bucket.numel:
+            raise ValueError(f"FusedAdam.load_state_dict: {state['numel']} parameters in the checkpoint, "
+                             f'{self.bucket.numel} in the bucket')
+        with torch.no_grad():
+            self.exp_avg.copy_(state['exp_avg'])
+            self.exp_avg_sq.copy_(state['exp_avg_sq'])
+            self.steps = int(state['step'])
+            if self.step_dev is not None:
+                self.step_dev.fill_(self.steps)
+        self.lr, self.eps = float(state['lr']), float(state['eps'])
+        self.betas = (float(state['betas'][0]), float(state['betas'][1]))
+
     def zero_grad(self, set_to_none=False):
         self.bucket.zero_grad()
 
     def step(self, grad_scale=1.0, gather=True):
+        from .gp.module import transform_cache_active
+        if transform_cache_active():
+            raise RuntimeError('FusedAdam.step() inside a transform_cache scope: the raw-pointer Adam kernel does not '
+                               'bump parameter versions, so the cached softplus values would go stale')
         if gather:
             self.bucket.gather_grads()
+        else:
+            self.bucket.check_homed()
         self.steps += 1
         if self.step_dev is not None:
             self.step_dev.add_(1)

@@ -25,13 +25,17 @@ def tr(x):
 
 
 def mv(matrix, vector, invert=False):
-    """matrix @ vector, or matrix^-1 vector for SPD `matrix` when invert=True (GPU Cholesky)."""
+    """matrix @ vector, or matrix^-1 vector when invert=True.  The reference's torch.linalg.solve (utils/functional.py:33)
+    takes any invertible matrix; its hot path only ever passes K + noise I, so this is a Cholesky solve on the GPU and
+    a matrix that is not symmetric positive definite raises NotPSDError (after psd_safe_cholesky's jitter retries)
+    instead of being LU-factored."""
     from nsgp import ops
     if matrix.is_cuda:
         rhs = vector.unsqueeze(-1)
         if not invert:
             return ops.matmul(matrix, rhs).squeeze(-1)
-        W, _ = ops.chol_inv(matrix.contiguous())
+        from nsgp.gp.utils.cholesky import chol_inv_safe
+        W = chol_inv_safe(matrix.contiguous())     # reads `info`: a matrix that is not SPD raises NotPSDError
         return ops.matmul(W, ops.matmul(W, rhs, a_lower=True), True, False, a_lower=True).squeeze(-1)
     if invert:
         raise ops.BackendError('fn.mv(invert=True) runs on the MI355X Cholesky: move the operands to the GPU')

@@ -49,3 +49,53 @@ def test_fit_runs_to_max_iters_without_logdir_and_freeze_fixes_parameters():
     assert res['iterations'] == 25 and not res['stopped_early']
     assert torch.equal(model.bias.detach(), b0)
     assert res['best_iteration'] >= 0
+
+
+def test_fit_raises_on_a_non_finite_objective_before_stepping(tmp_path):
+    """a NaN loss makes `change < threshold` false forever; fit() must stop before optimizer.step() instead of
+    writing NaN parameters to final.tar."""
+    import pytest
+    from nsgp.harness import fit
+    model, loss_fn = _problem()
+    calls = {'n': 0}
+
+    def nan_after_3():
+        calls['n'] += 1
+        loss = loss_fn()
+        return loss * float('nan') if calls['n'] > 3 else loss
+    opt = torch.optim.SGD(model.parameters(), lr=0.05)
+    with pytest.raises(FloatingPointError, match='objective is nan at iteration 3'):
+        fit(model, nan_after_3, opt, max_iters=50, threshold=0.0, logdir=str(tmp_path))
+    assert all(torch.isfinite(p).all() for p in model.parameters())
+    best = torch.load(os.path.join(str(tmp_path), 'best.tar'), weights_only=True)
+    assert best['i'] <= 2 and all(torch.isfinite(v).all() for v in best['model'].values())
+
+
+def test_fused_adam_state_dict_round_trip_and_bucket_homing():
+    """FusedAdam.state_dict()/load_state_dict() (plain tensors, in-place restore) and FlatBucket noticing a
+    parameter that was moved out of the flat buffer.  CPU-level: no kernel is launched."""
+    import pytest
+    from nsgp.optim import FlatBucket, FusedAdam
+    torch.manual_seed(1)
+    lin = torch.nn.Linear(5, 3)
+    opt = FusedAdam(lin.parameters(), lr=0.02, capturable=False)
+    opt.exp_avg.normal_(); opt.exp_avg_sq.uniform_(); opt.steps = 17
+    sd = opt.state_dict()
+    assert set(sd) == {'step', 'exp_avg', 'exp_avg_sq', 'lr', 'betas', 'eps', 'numel'}
+    buf = __import__('io').BytesIO()
+    torch.save(sd, buf); buf.seek(0)
+    sd2 = torch.load(buf, weights_only=True)                       # loads without unpickling arbitrary objects
+    lin2 = torch.nn.Linear(5, 3)
+    opt2 = FusedAdam(lin2.parameters(), lr=0.5)
+    ptr = opt2.exp_avg.data_ptr()
+    opt2.load_state_dict(sd2)
+    assert opt2.exp_avg.data_ptr() == ptr                            # in place: a captured hipGraph stays valid
+    assert opt2.steps == 17 and opt2.lr == 0.02 and torch.equal(opt2.exp_avg, opt.exp_avg)
+    assert torch.equal(opt2.exp_avg_sq, opt.exp_avg_sq) and opt2.param_groups[0]['lr'] == 0.02
+    with pytest.raises(ValueError, match='parameters in the checkpoint'):
+        FusedAdam(torch.nn.Linear(2, 2).parameters()).load_state_dict(sd2)
+    bucket = FlatBucket(list(lin2.parameters()))
+    bucket.check_homed()
+    lin2.double()                                                    # re-allocates p.data outside the flat buffer
+    with pytest.raises(RuntimeError, match='moved out of the flat buffer'):
+        bucket.check_homed()

@@ -135,3 +135,35 @@ def test_planner_queries_of_the_c_abi():
     assert lib.nsgp_svgp_lqbar_workspace(1, 64, 64, 4) == 0
     assert lib.nsgp_trtri_workspace(64, 3, 8) == 0 and lib.nsgp_trtri_workspace(1024, 3, 8) == 3 * 1024 * 1024 * 8
     assert lib.nsgp_rbf_periodic_build_bwd_workspace(1, 215, 215, 1, 8) > 0
+
+
+@pytest.mark.parametrize('name', ['uib_spatial', 'khyber_time_series'])
+def test_product_dataprep_matches_reference_goldens(golden_dir, data_dir, name):
+    """the PRODUCT's utils.dataprep (not the oracle's copy) against tests/golden/ref_dataprep.npz, which
+    was written by running the reference's own utils/dataprep.py:9-52 (tests/golden/make_reference_goldens.py)."""
+    import os
+    import numpy as np
+    import utils.dataprep as dp
+    z = np.load(os.path.join(golden_dir, 'ref_dataprep.npz'))
+    data = dp.download_data(os.path.join(data_dir, name + '.csv'))
+    x, y, mx, sx, my, sy = dp.whitening_transform(data)
+    for got, key in ((x, 'x'), (y, 'y'), (mx, 'meanx'), (sx, 'stdx'), (my, 'meany'), (sy, 'stdy')):
+        assert torch.equal(got, torch.from_numpy(z[f'{name}_{key}'])), key
+    trx, try_, tex, tey = dp.train_test_split(x, y, 0.8)
+    assert len(trx) == int(z[f'{name}_ntrain'])
+    assert torch.equal(trx[-3:], torch.from_numpy(z[f'{name}_train_x_tail']))
+    assert torch.equal(tey[:3], torch.from_numpy(z[f'{name}_test_y_head']))
+
+
+def test_product_functional_elementwise_helpers_match_reference_goldens(golden_dir):
+    """dot / t / op / non-inverting mv of the product's utils.functional on CPU tensors (device-agnostic torch) against
+    the reference-generated ref_functional.npz; mv(invert=True) is GPU-only (tests/test_gpu_parity_r2.py)."""
+    import os
+    import numpy as np
+    import utils.functional as fn
+    z = np.load(os.path.join(golden_dir, 'ref_functional.npz'))
+    T = {k: torch.from_numpy(z[k]) for k in z.files}
+    assert torch.equal(fn.dot(T['v1'], T['v2']), T['dot'])
+    assert torch.equal(fn.t(T['A']), T['t'])
+    assert torch.allclose(fn.mv(T['A'], T['b']), T['mv'], rtol=1e-14, atol=1e-14)
+    assert torch.equal(fn.op(T['e1'], T['e2']), T['op']) and torch.equal(fn.op(T['e1']), T['op_self'])
