@@ -34,7 +34,7 @@ def test_product_functional_on_gpu_matches_reference_goldens(golden_dir):
     import utils.functional as fn
     z = np.load(os.path.join(golden_dir, 'ref_functional.npz'))
     T = {k: torch.from_numpy(z[k]).cuda() for k in z.files}
-    assert torch.equal(fn.dot(T['v1'], T['v2']), T['dot'])
+    assert torch.allclose(fn.dot(T['v1'], T['v2']), T['dot'], rtol=1e-14, atol=1e-14)    # device summation order
     assert torch.equal(fn.t(T['A']), T['t'])
     assert torch.allclose(fn.mv(T['A'], T['b']), T['mv'], rtol=1e-13, atol=1e-13)       # MFMA f64 summation order
     assert torch.allclose(fn.mv(T['A'], T['b'], invert=True), T['mv_inv'], rtol=1e-12, atol=1e-13)
@@ -76,8 +76,15 @@ def test_matrix_variate_normal_prior_values_match_oracle():
     # a matrix and its "other vec order" twin get different densities
     assert abs(float(pr.log_prob(H.cuda())) - float(pr.log_prob(H.T.reshape(n, d).cuda()))) > 1e-3
     assert torch.allclose(pr.kron_cov.cpu().double(), ref.kron_cov, rtol=1e-6, atol=1e-7)
-    assert torch.allclose(pr.kron_cov_inv.cpu().double(), ref.kron_cov_inv.double(), rtol=2e-3,
-                          atol=2e-3 * float(ref.kron_cov_inv.abs().max()))             # float32 inverse, kappa ~ 1e5
+    # kron_cov_inv = kron(col^-1, (row + 1e-5 I)^-1): the reference inverts the float32 row covariance in float32
+    # (kappa ~ 1e5: a few 1e-3 of its own largest entry off); this path inverts it with the float64 MFMA Cholesky and
+    # rounds once.  Held to the float64 inverse at float32 round-off, and to the reference-style float32 inverse at that
+    # inverse's own accuracy.
+    rowj64 = row.double() + 1e-5 * torch.eye(n, dtype=F64)
+    inv64 = torch.kron(torch.linalg.inv(col.double()), torch.linalg.inv(rowj64))
+    scale = float(inv64.abs().max())
+    assert float((pr.kron_cov_inv.cpu().double() - inv64).abs().max()) < 1e-5 * scale
+    assert float((ref.kron_cov_inv.double() - inv64).abs().max()) < 2e-2 * scale
     # sample_n: shape, and first two moments of many draws against the Kronecker covariance
     torch.manual_seed(0)
     S = torch.stack([pr.sample_n(1).reshape(-1) for _ in range(64)])
@@ -116,6 +123,9 @@ def test_sparse_spatiotemporal_nonstationary_matches_oracle(data_dir):
     g = torch.Generator().manual_seed(11)
     # 30 inducing points with distinct times / cells (a plain subset repeats time stamps: singular temporal Kzz)
     z = xtr[torch.randperm(len(xtr), generator=g)[:30]].clone() + 0.15 * torch.randn(30, 3, generator=g, dtype=F64)
+    # the subset holds 4 distinct (train) time stamps: spread the inducing times so that the temporal Kzz (a smooth
+    # RBF x Periodic kernel on 30 times) is factorable without psd_safe_cholesky's jitter ladder
+    z[:, 0] = torch.linspace(-1.6, 1.6, 30, dtype=F64)[torch.randperm(30, generator=g)] + 0.01 * torch.randn(30, generator=g, dtype=F64)
     prior = LogNormalPriorProcess(input_dim=2, active_dims=(0, 1)).double()
     prior.covar_module.base_kernel.lengthscale = 1.3 * torch.ones_like(prior.covar_module.base_kernel.lengthscale)
     prior.mean_module.constant = torch.nn.Parameter(math.log(0.3) * torch.ones_like(prior.mean_module.constant))
@@ -128,6 +138,10 @@ def test_sparse_spatiotemporal_nonstationary_matches_oracle(data_dir):
     with torch.no_grad():
         model.log_ell_z.add_(0.1 * torch.randn(2, 30, generator=g, dtype=F64).cuda())
         lik.noise = 0.2
+        tkk = model.temporal_covar_module.base_kernel.base_kernel.kernels
+        tkk[0].lengthscale = 0.12 * torch.ones_like(tkk[0].lengthscale)        # kappa(temporal Kzz) ~ 1e3
+        tkk[1].lengthscale = 0.8 * torch.ones_like(tkk[1].lengthscale)
+        tkk[1].period_length = 0.9 * torch.ones_like(tkk[1].period_length)
     model.train(); lik.train()
     mll = gpytorch.mlls.ExactMarginalLogLikelihood(lik, model)
     val = mll(model(model.train_inputs[0]), model.train_targets)
