@@ -20,6 +20,7 @@
 // A-adjoint assembled in the epilogue, an operand scaled along k in the loader -- the elementwise passes of
 // VariationalStrategy.forward and of its backward never run as separate kernels.
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -58,6 +59,9 @@ struct GemmArgs {
     int64_t ksplit, kper;         // K-slices (kper is a multiple of BK)
     int64_t slab;                 // elements per (slice) slab = nb1*nb2*M*N when ksplit > 1
     int flags;
+    int nbk;                      // batch x K-slices (the logical extent of grid.y)
+    int xcd_chunk;                // > 0: chunked XCD placement of a split-K launch, workgroups per XCD (see the kernel)
+    int xcd_group;                // > 0: XCD-aware tile order with this many tile rows per group (see the kernel)
     int vecA, vecB;               // 16-byte vector global loads allowed for A / B
     int modeA, modeB;             // 0: contiguous along k, 1: contiguous along m (n)
 };
@@ -93,100 +97,142 @@ template <typename T> __device__ __forceinline__ Frag4<T> ldg4(const T* p) {
     return f;
 }
 
-// Load 4 elements of an operand tile.  (r, k) is the element's (m|n, k) position; the 4 elements run
-// along k (mode 0) or along r (mode 1).  `lo`/`up`: zero where k > r (lower) / k < r (upper) for A,
-// and for B (r = n): "B lower" zero where n > k, "B upper" zero where n < k.
-template <typename T>
-__device__ __forceinline__ Frag4<T> load_operand4(const T* base, int64_t sr, int64_t sk, int64_t r, int64_t k,
-                                                  int64_t R, int64_t kend, int mode, int vec, bool zero_k_gt_r,
-                                                  bool zero_k_lt_r) {
-    Frag4<T> f;
-    if (mode == 0) {
-        if (vec && r < R && k + 3 < kend) {
-            f = ldg4(base + r * sr + k);
-        } else {
+// Operand tile loader.  A thread owns P four-element pieces of the BR x BK operand tile (R = m for A, n for B):
+//   MODE 0 (operand contiguous along k): piece p = row r0 + p * RS, columns k0 .. k0 + 3
+//   MODE 1 (contiguous along r)        : piece p = rows r0 .. r0 + 3, column k0 + p * KS
+// Three paths per K-tile: `fast` (whole tile in bounds, 16-byte aligned, off the diagonal: bare vector loads),
+// `fast + mask` (diagonal blocks of a triangular operand: vector loads, then zeros by 32-bit compares on tile-local
+// coordinates) and `edge` (ragged or unaligned tiles: scalar loads with bounds, rare).  zgt / zlt: zero where
+// k > r / k < r (r the global row of A, or the global column of B).
+template <typename T, int MODE, int BR, int BK, int P>
+struct TileLoader {
+    static constexpr int TPK = BK / 4, TPR = BR / 4;
+    static constexpr int RS = MODE == 0 ? 256 / TPK : 0;      // row step between pieces
+    static constexpr int KS = MODE == 0 ? 0 : 256 / TPR;      // k step between pieces
+    int r0, k0;                                               // tile-local coordinates of piece 0
+    const T* cur;                                             // fast-path pointer of piece 0 at the current K-tile
+    int64_t pstep, kstep;                                     // element strides: between pieces, per k
+    __device__ __forceinline__ void init(int tid, const T* base, int64_t row0, int64_t sr, int64_t sk, int64_t kbeg) {
+        if (MODE == 0) { r0 = tid / TPK; k0 = (tid % TPK) * 4; }
+        else { r0 = (tid % TPR) * 4; k0 = tid / TPR; }
+        kstep = sk;
+        pstep = MODE == 0 ? RS * sr : KS * sk;
+        cur = base + (row0 + r0) * sr + (kbeg + k0) * sk;
+    }
+    __device__ __forceinline__ int prow(int p) const { return r0 + p * RS; }
+    __device__ __forceinline__ int pk(int p) const { return k0 + p * KS; }
+    // fast path: the whole tile is in bounds and every piece is a 16-byte aligned vector (koff = k offset from kbeg)
+    __device__ __forceinline__ void load_fast(Frag4<T>* f, int64_t koff) const {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) f.v[e] = (r < R && k + e < kend) ? base[r * sr + (k + e) * sk] : T(0);
-        }
+        for (int p = 0; p < P; ++p) f[p] = ldg4(cur + p * pstep + koff * kstep);
+    }
+    // edge path: ragged / unaligned tiles, element by element with bounds (rrem rows, krem columns are valid)
+    __device__ __forceinline__ void load_edge(Frag4<T>* f, const T* base, int64_t row0, int64_t sr, int64_t sk, int64_t k0g,
+                                              int rrem, int krem) const {
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = prow(p) + (MODE == 0 ? 0 : e), k = pk(p) + (MODE == 0 ? e : 0);
+                f[p].v[e] = (r < rrem && k < krem) ? base[(row0 + r) * sr + (k0g + k) * sk] : T(0);
+            }
+    }
+    // diagonal block of a triangular operand: zero where k > r (zgt) / k < r (zlt), d = global k0 - global row0.
+    // Applied per piece on its way INTO LDS (not right behind the load: that would wait for the load on the spot).
+    __device__ __forceinline__ void mask_piece(Frag4<T>& f, int p, int d, bool zgt, bool zlt) const {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            if (zero_k_gt_r && k + e > r) f.v[e] = T(0);
-            if (zero_k_lt_r && k + e < r) f.v[e] = T(0);
-        }
-    } else {
-        if (vec && k < kend && r + 3 < R) {
-            f = ldg4(base + k * sk + r);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) f.v[e] = (k < kend && r + e < R) ? base[(r + e) * sr + k * sk] : T(0);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (zero_k_gt_r && k > r + e) f.v[e] = T(0);
-            if (zero_k_lt_r && k < r + e) f.v[e] = T(0);
+            const int r = prow(p) + (MODE == 0 ? 0 : e), k = pk(p) + (MODE == 0 ? e : 0) + d;
+            const bool z = (zgt && k > r) || (zlt && k < r);
+            f.v[e] = z ? T(0) : f.v[e];                          // select, not a branch
         }
     }
-    return f;
-}
+};
 
 // MODE_A / MODE_B: 0 = operand contiguous along k, 1 = contiguous along m (n).
-template <typename T, int BM, int BN, int BK, int MODE_A, int MODE_B, int EPI = 0, int KSC = 0, int PF = 0>
+// EDGE = 0: every tile of the launch is whole and vector-loadable (M % BM == N % BN == K % BK == 0, 16-byte aligned
+// operands: the host checks) -- no bounds code is compiled in; EDGE = 1: ragged / unaligned shapes, element-wise loads.
+template <typename T, int BM, int BN, int BK, int MODE_A, int MODE_B, int EPI = 0, int KSC = 0, int PF = 0, int EDGE = 1>
 __global__ __launch_bounds__(256, (BM == 128 && BN == 64) ? 3 : 2) void gemm_kernel(GemmArgs g, T alpha, const T* __restrict__ A,
                                                    const T* __restrict__ B, T beta, T* __restrict__ C,
                                                    T* __restrict__ slabs, Epi ep) {
     using MF = Mfma<T>;
     constexpr int MT = MF::MT, KS = MF::KS, NKK = BK / KS;
-    constexpr int KCH = NKK < 8 ? NKK : 8;                      // k-steps whose fragments are prefetched together
+    constexpr int KCH = NKK < 8 ? NKK : 8;                      // k-steps whose fragments are prefetched together (PF2)
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int TM = WM / MT, TN = WN / MT;
     constexpr int PADA = (MODE_A == 0 && sizeof(T) == 4) ? 1 : MF::PAD;
     constexpr int PADB = (MODE_B == 0 && sizeof(T) == 4) ? 1 : MF::PAD;
     constexpr int LDA = BM + PADA, LDB = BN + PADB;
-    constexpr int PA = BM * BK / 1024, PB = BN * BK / 1024;     // 4-element fragments per thread
-    constexpr int TPRA = BM / 4, TPRB = BN / 4;                 // threads per k-row in mode 1
-    constexpr int TPK = BK / 4;                                 // threads per row in mode 0 (full BK bytes)
+    constexpr int PA = BM * BK / 1024, PB = BN * BK / 1024;     // 4-element pieces per thread
     // all LDS in ONE dynamic region (the 128x128x32 f32 tile needs 66 KB > the 64 KB static limit)
     extern __shared__ __attribute__((aligned(32))) unsigned char gemm_smem[];
     T (*As)[BK * LDA] = reinterpret_cast<T (*)[BK * LDA]>(gemm_smem);
     T (*Bs)[BK * LDB] = reinterpret_cast<T (*)[BK * LDB]>(gemm_smem + 2 * BK * LDA * sizeof(T));
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
-    // tile id -> (bm, bn): bn fastest, so the workgroups in flight share one A row panel (L2 resident) and
-    // stream disjoint B column panels.  Triangular operands / outputs make the work per tile uneven:
-    //  * rows with the longest K range are issued first (longest-processing-time order);
-    //  * the column index is rotated by the row index.  Workgroups are dealt round-robin to the 8 XCDs
-    //    (id % 8), so without the rotation an XCD owns fixed tile COLUMNS -- with a lower-triangular
-    //    output and 8 tile columns XCD 0 gets 8 active tiles per slice and XCD 7 one (measured: the
-    //    lower-only M=N=1024, K=40960 product took 879 us, the FULL product 780 us).
-    const int64_t tid_lin = blockIdx.x;
-    int64_t bm, bn;
+    // 32-bit tile arithmetic (the host checks tiles_m * tiles_n < 2^31): the 64-bit divisions of the first version
+    // cost every workgroup ~1 us of scalar code before its first load.
+    const int tiles_m = (int)g.tiles_m, tiles_n = (int)g.tiles_n;
+    int tid_lin = (int)blockIdx.x, zz = (int)blockIdx.y;
+    if (g.xcd_chunk > 0) {
+        // Long-K products with a small output (Lqbar = A diag(v) C^T, Wbar = Abar Kzx^T; split along K into slabs): every
+        // (tile, slice) workgroup streams a 128-row panel of both operands once, and the tiles of one slice read the SAME
+        // k range.  Dealt round-robin to the XCDs they shared nothing below the Infinity Cache (4.5x the operand bytes
+        // through the fabric, ~5 TB/s: these launches were bandwidth-bound).  Here XCD x takes the contiguous chunk
+        // [x * per, (x + 1) * per) of the slice-major order, so the tiles of a slice sit on one XCD (two at a chunk
+        // boundary), walk k in step and share each operand K-tile through that L2.  Speed only.
+        const int L = zz * (int)gridDim.x + tid_lin;
+        const int logical = (L & 7) * g.xcd_chunk + (L >> 3);
+        const int ntile = (int)gridDim.x;
+        tid_lin = logical % ntile;
+        zz = logical / ntile;
+        if (zz >= g.nbk) return;                          // padding of the last chunk
+    }
+    int bm, bn;
     if (g.flags & NSGP_GEMM_C_LOWER) {
         // compact enumeration of the ACTIVE tiles only (n0 <= m0 + BM - 1): launching the strictly-upper
         // tiles as no-op workgroups perturbs the dispatcher's CU placement (measured: lower-only product
         // no faster than the full one, CUs ~58 % busy).  Rows 0..T-1 form a triangle, the rest are full.
-        const int64_t TT = g.tiles_m < g.tiles_n ? g.tiles_m : g.tiles_n;
-        const int64_t tri = TT * (TT + 1) / 2;
+        const int TT = tiles_m < tiles_n ? tiles_m : tiles_n;
+        const int tri = TT * (TT + 1) / 2;
         if (tid_lin < tri) {
-            int64_t r = (int64_t)((sqrtf(8.0f * (float)tid_lin + 1.0f) - 1.0f) * 0.5f);
+            int r = (int)((sqrtf(8.0f * (float)tid_lin + 1.0f) - 1.0f) * 0.5f);
             while (r * (r + 1) / 2 > tid_lin) --r;
             while ((r + 1) * (r + 2) / 2 <= tid_lin) ++r;
             bm = r; bn = tid_lin - r * (r + 1) / 2;
         } else {
-            const int64_t q = tid_lin - tri;
-            bm = TT + q / g.tiles_n; bn = q % g.tiles_n;
+            const int q = tid_lin - tri;
+            bm = TT + q / tiles_n; bn = q % tiles_n;
         }
+    } else if (g.xcd_group > 0) {
+        // XCD-aware order for a triangular A operand (SVGP projections, n >> M): workgroups are dealt round-robin to
+        // the 8 XCDs (id % 8), each with its own 4 MiB L2.  Logical order = column panel major, tile rows fastest
+        // within a row group, and XCD x owns the column panels  bn = 8 * (j / R) + x : the R row tiles of a column
+        // panel run on ONE XCD at the same time and walk k in step, so a K-tile of the B panel is fetched once from
+        // the fabric and hit R - 1 times in that L2 (the bn-fastest order re-fetched every B panel once per tile row:
+        // 4.5x the operand bytes, profiles/r01/gemm_hbm_pmc_v3.txt).  Row groups run longest K range first (the
+        // tail of the launch is made of short tiles).  Speed only: correctness does not depend on the placement.
+        const int R = g.xcd_group;                       // rows per group (divides tiles_m)
+        const int x = tid_lin & 7, j = tid_lin >> 3;
+        const int panels8 = (tiles_n + 7) >> 3;          // column panels per XCD
+        const int per_group = panels8 * R;               // tiles per XCD and row group
+        const int grp = j / per_group, jj = j - grp * per_group;
+        bn = 8 * (jj / R) + x;
+        bm = grp * R + (jj % R);
+        if (bn >= tiles_n) return;                       // padding of the last 8-panel block
     } else {
-        const int64_t brow = tid_lin / g.tiles_n;
+        const int brow = tid_lin / tiles_n;
         // (j - row) mod tiles_n: spreads a triangular B operand's heavy columns over the XCDs (id % 8)
-        bm = brow; bn = (tid_lin % g.tiles_n + g.tiles_n - brow % g.tiles_n) % g.tiles_n;
+        bm = brow; bn = (tid_lin % tiles_n + tiles_n - brow % tiles_n) % tiles_n;
     }
-    if (g.flags & NSGP_GEMM_A_LOWER) bm = g.tiles_m - 1 - bm;          // large m = long K range
-    if (g.flags & NSGP_GEMM_B_UPPER) bn = g.tiles_n - 1 - bn;          // large n = long K range
-    const int64_t z = blockIdx.y;
-    const int64_t slice = z % g.ksplit, bb = z / g.ksplit;
-    const int64_t b1 = bb / g.nb2, b2 = bb % g.nb2;
-    const int64_t m0 = bm * BM, n0 = bn * BN;
+    if (g.flags & NSGP_GEMM_A_LOWER) bm = tiles_m - 1 - bm;            // large m = long K range
+    if (g.flags & NSGP_GEMM_B_UPPER) bn = tiles_n - 1 - bn;            // large n = long K range
+    const int ksp = (int)g.ksplit, nb2i = (int)g.nb2;
+    const int64_t slice = zz % ksp, bb = zz / ksp;
+    const int64_t b1 = (int)bb / nb2i, b2 = (int)bb % nb2i;
+    const int64_t m0 = (int64_t)bm * BM, n0 = (int64_t)bn * BN;
 
     const T* Ab = A + b1 * g.sa1 + b2 * g.sa2;
     const T* Bb = B + b1 * g.sb1 + b2 * g.sb2;
@@ -204,7 +250,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64) ? 3 : 2) void gemm_ker
     if (bU) { const int64_t e = n0 + BN; if (e < kend) kend = e; }                 // k <= n
     const bool skip_block = cL && (n0 > m0 + BM - 1);
     if (skip_block) kend = kbeg;
-    const int64_t nt = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+    const int nt = kend > kbeg ? (int)((kend - kbeg + BK - 1) / BK) : 0;
 
     typename MF::acc_t acc[TM][TN];
 #pragma unroll
@@ -214,30 +260,11 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64) ? 3 : 2) void gemm_ker
 #pragma unroll
             for (int r = 0; r < MF::NREG; ++r) acc[i][j][r] = T(0);
 
-    // per-thread tile coordinates of its 4-element fragments
-    int ar[PA], ak[PA], br[PB], bk[PB];
-#pragma unroll
-    for (int p = 0; p < PA; ++p) {
-        if (MODE_A == 0) { ar[p] = p * (256 / TPK) + tid / TPK; ak[p] = (tid % TPK) * 4; }
-        else { ar[p] = (tid % TPRA) * 4; ak[p] = p * (256 / TPRA) + tid / TPRA; }
-    }
-#pragma unroll
-    for (int p = 0; p < PB; ++p) {
-        if (MODE_B == 0) { br[p] = p * (256 / TPK) + tid / TPK; bk[p] = (tid % TPK) * 4; }
-        else { br[p] = (tid % TPRB) * 4; bk[p] = p * (256 / TPRB) + tid / TPRB; }
-    }
-    // fast path: every 16-byte fragment of the tile is in bounds, aligned and unmasked
-    const bool fastA = g.vecA && (m0 + BM <= g.M);
-    const bool fastB = g.vecB && (n0 + BN <= g.N);
-    const T* pa[PA];
-    const T* pb[PB];
-#pragma unroll
-    for (int p = 0; p < PA; ++p)
-        pa[p] = MODE_A == 0 ? Ab + (m0 + ar[p]) * g.sam + ak[p] : Ab + (m0 + ar[p]) + (int64_t)ak[p] * g.sak;
-#pragma unroll
-    for (int p = 0; p < PB; ++p)
-        pb[p] = MODE_B == 0 ? Bb + (n0 + br[p]) * g.sbn + bk[p] : Bb + (n0 + br[p]) + (int64_t)bk[p] * g.sbk;
-    const int64_t stepA = MODE_A == 0 ? 1 : g.sak, stepB = MODE_B == 0 ? 1 : g.sbk;
+    TileLoader<T, MODE_A, BM, BK, PA> la;
+    TileLoader<T, MODE_B, BN, BK, PB> lb;
+    la.init(tid, Ab, m0, g.sam, g.sak, kbeg);
+    lb.init(tid, Bb, n0, g.sbn, g.sbk, kbeg);
+    const int mrem = (int)(g.M - m0 < BM ? g.M - m0 : BM), nrem = (int)(g.N - n0 < BN ? g.N - n0 : BN);
 
     // PF = 1 (float64, grids of at most one round): the tile is small (16 MFMAs per wave and K-tile, 0.25 us),
     // one K-tile of prefetch does not cover a global-load latency, so TWO K-tiles are kept in flight in two
@@ -249,79 +276,83 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64) ? 3 : 2) void gemm_ker
     const T* ksb = KSC ? reinterpret_cast<const T*>(ep.ks) + bb * g.K : nullptr;
     const bool ks_vec = KSC && ((uintptr_t)ksb % (4 * sizeof(T)) == 0);
 
-    auto gload = [&](int64_t k0, Frag4<T>* ra, Frag4<T>* rb) {
-        const bool kfull = k0 + BK <= kend;
-        const bool a_diag = (aL || aU) && (k0 < m0 + BM) && (k0 + BK > m0);
-        const bool b_diag = (bL || bU) && (k0 < n0 + BN) && (k0 + BK > n0);
-        if (fastA && kfull && !a_diag) {
-#pragma unroll
-            for (int p = 0; p < PA; ++p) ra[p] = ldg4(pa[p] + k0 * stepA);
-        } else {
-#pragma unroll
-            for (int p = 0; p < PA; ++p)
-                ra[p] = load_operand4<T>(Ab, g.sam, g.sak, m0 + ar[p], k0 + ak[p], g.M, kend, MODE_A, g.vecA, aL, aU);
-        }
-        if (fastB && kfull && !b_diag) {
-#pragma unroll
-            for (int p = 0; p < PB; ++p) rb[p] = ldg4(pb[p] + k0 * stepB);
-        } else {
-#pragma unroll
-            for (int p = 0; p < PB; ++p)   // B(k,n): "lower" zero where n > k <=> k < r ; "upper" zero where k > r
-                rb[p] = load_operand4<T>(Bb, g.sbn, g.sbk, n0 + br[p], k0 + bk[p], g.N, kend, MODE_B, g.vecB, bU, bL);
-        }
-        if constexpr (KSC != 0) {
-            if (MODE_B == 0) {
-                // every fragment of this thread covers the same 4 k's (bk[p] does not depend on p): ONE load
-                const int64_t k = k0 + bk[0];
-                if (ks_vec && k + 3 < kend) {
-                    rks[0] = ldg4(ksb + k);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) rks[0].v[e] = k + e < kend ? ksb[k + e] : T(0);
-                }
+    // per staging register set (PF2 keeps two tiles in flight): is the held tile a diagonal block of A / B, and its
+    // k0 - row0 offsets
+    bool st_adiag[2] = {false, false}, st_bdiag[2] = {false, false};
+    int st_ad[2] = {0, 0}, st_bd[2] = {0, 0};
+    auto load_ks = [&](int64_t k0) __attribute__((always_inline)) {
+        if (MODE_B == 0) {
+            // every piece of this thread covers the same 4 k's: ONE load
+            const int64_t k = k0 + lb.k0;
+            if (ks_vec && k + 3 < kend) {
+                rks[0] = ldg4(ksb + k);
             } else {
 #pragma unroll
-                for (int p = 0; p < PB; ++p) {
-                    const int64_t k = k0 + bk[p];
-                    rks[p].v[0] = k < kend ? ksb[k] : T(0);
-                }
+                for (int e = 0; e < 4; ++e) rks[0].v[e] = k + e < kend ? ksb[k + e] : T(0);
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < PB; ++p) {
+                const int64_t k = k0 + lb.pk(p);
+                rks[p].v[0] = k < kend ? ksb[k] : T(0);
             }
         }
     };
-    auto sstore = [&](int buf, Frag4<T>* ra, Frag4<T>* rb) {
-#pragma unroll
-        for (int p = 0; p < PA; ++p) {
-            if (MODE_A == 0) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) As[buf][(ak[p] + e) * LDA + ar[p]] = ra[p].v[e];
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) As[buf][ak[p] * LDA + ar[p] + e] = ra[p].v[e];
-            }
+    auto gload = [&](int t, Frag4<T>* ra, Frag4<T>* rb, int set = 0) __attribute__((always_inline)) {
+        const int64_t k0 = kbeg + (int64_t)t * BK;
+        if constexpr (EDGE == 0) {
+            la.load_fast(ra, (int64_t)t * BK);
+            lb.load_fast(rb, (int64_t)t * BK);
+        } else {
+            const int64_t left = kend - k0;
+            const int krem = (int)(left < BK ? left : BK);
+            la.load_edge(ra, Ab, m0, g.sam, g.sak, k0, mrem, krem);
+            lb.load_edge(rb, Bb, n0, g.sbn, g.sbk, k0, nrem, krem);
         }
-        if constexpr (KSC != 0) {
+        // diagonal blocks of triangular operands are zeroed when the pieces are stored (store_piece), so that nothing
+        // waits for these loads here
+        st_adiag[set] = (aL || aU) && (k0 < m0 + BM) && (k0 + BK > m0);
+        st_bdiag[set] = (bL || bU) && (k0 < n0 + BN) && (k0 + BK > n0);
+        st_ad[set] = (int)(k0 - m0);
+        st_bd[set] = (int)(k0 - n0);
+        if constexpr (KSC != 0) load_ks(k0);
+    };
+    // one four-element piece of the staged tile -> LDS (k-major images As[k][m], Bs[k][n])
+    constexpr int NPIECE = PA + PB;
+    auto store_piece = [&](int buf, int q, Frag4<T>* ra, Frag4<T>* rb, auto masked_c, int set = 0) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_c)::value;
+        if (q < PA) {
+            const int p = q;
+            if constexpr (MASKED) {
+                if (st_adiag[set]) la.mask_piece(ra[p], p, st_ad[set], aL, aU);
+            }
+            T* dst = &As[buf][la.pk(p) * LDA + la.prow(p)];
 #pragma unroll
-            for (int p = 0; p < PB; ++p)
+            for (int e = 0; e < 4; ++e) dst[MODE_A == 0 ? e * LDA : e] = ra[p].v[e];
+        } else {
+            const int p = q - PA;
+            if constexpr (MASKED) {          // B(k, n): "lower" zero where n > k <=> k < r ; "upper" zero where k > r
+                if (st_bdiag[set]) lb.mask_piece(rb[p], p, st_bd[set], bU, bL);
+            }
+            if constexpr (KSC != 0) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) rb[p].v[e] *= (MODE_B == 0 ? rks[0].v[e] : rks[p].v[0]);
-        }
-#pragma unroll
-        for (int p = 0; p < PB; ++p) {
-            if (MODE_B == 0) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) Bs[buf][(bk[p] + e) * LDB + br[p]] = rb[p].v[e];
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) Bs[buf][bk[p] * LDB + br[p] + e] = rb[p].v[e];
             }
+            T* dst = &Bs[buf][lb.pk(p) * LDB + lb.prow(p)];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[MODE_B == 0 ? e * LDB : e] = rb[p].v[e];
         }
+    };
+    auto sstore = [&](int buf, Frag4<T>* ra, Frag4<T>* rb, int set = 0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < NPIECE; ++q) store_piece(buf, q, ra, rb, std::true_type{}, set);
     };
 
     const int kr = MF::krow(lane), mc = MF::mcol(lane);
-    auto compute = [&](int buf) {
+    // old-style compute (fragments of KCH k-steps, then their MFMAs): kept for the float64 two-tiles-in-flight variant
+    auto compute = [&](int buf) __attribute__((always_inline)) {
         const T* as = &As[buf][kr * LDA + wm0 + mc];
         const T* bs = &Bs[buf][kr * LDB + wn0 + mc];
-        // operand fragments of KCH k-steps first (LDS latency overlaps the MFMA stream), then the MFMAs
 #pragma unroll
         for (int kc = 0; kc < NKK; kc += KCH) {
             T af[KCH][TM], bf[KCH][TN];
@@ -340,38 +371,180 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64) ? 3 : 2) void gemm_ker
                     for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(af[kk][i], bf[kk][j], acc[i][j]);
         }
     };
+
+    // ---- software-pipelined K-tile (the main loop of every variant but PF2) ----------------------------------------
+    // One wave must keep its SIMD's matrix pipe busy on its own: the two workgroups of a CU run the same program and
+    // fall into step, so whatever one wave exposes (LDS read latency in front of every k-step, the staging stores
+    // and the barrier at the end of a K-tile) the other exposes at the same moment (round 1: pipe 66-73 % busy,
+    // hipcc had sunk every fragment read to just before its MFMAs behind an lgkmcnt(0)).  Here, per k-step:
+    //   fragments of k-step ks+1 are read into the OTHER register set  ->  one piece of the next K-tile's staging
+    //   stores (second half of the tile only, so the global loads issued at its start have landed)  ->  the MFMAs of
+    //   k-step ks.  sched_barrier(0) pins that order; the waits hipcc inserts are then counted (the reads a k-step
+    //   consumes are a whole k-step old).
+    // `tmask` (bit i * TN + j): which MFMA tiles of the wave's TM x TN this K-tile touches -- diagonal blocks of
+    // triangular operands / lower-only outputs skip the MFMA tiles that lie entirely in the zero part.
+    constexpr int KS0 = NKK / 2;                                     // first k-step that carries staging stores
+    constexpr int PPS = (NPIECE + (NKK - KS0) - 1) / (NKK - KS0);    // pieces per k-step
+    constexpr int FULLMASK = (1 << (TM * TN)) - 1;
+    auto ktile = [&](int buf, bool stage, auto tmask_c, auto masked_c, Frag4<T>* ra, Frag4<T>* rb) __attribute__((always_inline)) {
+        constexpr int tmask = decltype(tmask_c)::value;          // compile-time: a runtime mask makes every MFMA conditional
+        const T* as = &As[buf][kr * LDA + wm0 + mc];             // and hipcc then keeps two copies of the accumulators
+        const T* bs = &Bs[buf][kr * LDB + wn0 + mc];
+        T af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[0][i] = as[i * MT];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[0][j] = bs[j * MT];
+#pragma unroll
+        for (int ks = 0; ks < NKK; ++ks) {
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ks + 1 < NKK) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[nxt][i] = as[(ks + 1) * KS * LDA + i * MT];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[nxt][j] = bs[(ks + 1) * KS * LDB + j * MT];
+            }
+            if (ks >= KS0 && stage) {
+#pragma unroll
+                for (int q = (ks - KS0) * PPS; q < (ks - KS0 + 1) * PPS && q < NPIECE; ++q) store_piece(buf ^ 1, q, ra, rb, masked_c);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    if constexpr ((tmask >> 0) != 0) {
+                        if ((tmask >> (i * TN + j)) & 1) acc[i][j] = MF::mma(af[cur][i], bf[cur][j], acc[i][j]);
+                    }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // MFMA-tile masks.  Block row q = wm0 / MT + i covers rows [m0 + q MT, m0 + (q + 1) MT); block column likewise.
+    int cmask_tile = FULLMASK;                       // lower-only output: tiles strictly above the diagonal are skipped
+    if (cL) {
+        cmask_tile = 0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                if (n0 + wn0 + j * MT <= m0 + wm0 + (i + 1) * MT - 1) cmask_tile |= 1 << (i * TN + j);
+    }
+    const bool cL_partial = cmask_tile != FULLMASK;      // a wave of a diagonal output tile with MFMA tiles to skip
+    auto tile_mask = [&](int64_t k0) __attribute__((always_inline)) {
+        int mk = cmask_tile;
+        if (aL || aU) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int64_t r0 = m0 + wm0 + i * MT;
+                const bool on = aL ? (k0 < r0 + MT) : (k0 + BK > r0);        // k <= row  /  k >= row
+                if (!on) mk &= ~(((1 << TN) - 1) << (i * TN));
+            }
+        }
+        if (bL || bU) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int64_t c0 = n0 + wn0 + j * MT;
+                const bool on = bU ? (k0 < c0 + MT) : (k0 + BK > c0);        // B(k, n): upper k <= n, lower k >= n
+                if (!on) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) mk &= ~(1 << (i * TN + j));
+                }
+            }
+        }
+        return mk;
+    };
     if constexpr (PF2) {
         if (nt > 0) {
-            gload(kbeg, ra0, rb0);
-            if (nt > 1) gload(kbeg + BK, ra1, rb1);
-            sstore(0, ra0, rb0);
+            gload(0, ra0, rb0, 0);
+            if (nt > 1) gload(1, ra1, rb1, 1);
+            sstore(0, ra0, rb0, 0);
             __syncthreads();
-            for (int64_t t = 0; t < nt; t += 2) {
+            for (int t = 0; t < nt; t += 2) {
                 // even step: set 0 is free (stored), set 1 holds tile t+1
-                if (t + 2 < nt) gload(kbeg + (t + 2) * BK, ra0, rb0);
+                if (t + 2 < nt) gload(t + 2, ra0, rb0, 0);
                 compute(0);
-                if (t + 1 < nt) sstore(1, ra1, rb1);
+                if (t + 1 < nt) sstore(1, ra1, rb1, 1);
                 __syncthreads();
                 if (t + 1 >= nt) break;
                 // odd step: set 1 is free, set 0 holds tile t+2
-                if (t + 3 < nt) gload(kbeg + (t + 3) * BK, ra1, rb1);
+                if (t + 3 < nt) gload(t + 3, ra1, rb1, 1);
                 compute(1);
-                if (t + 2 < nt) sstore(0, ra0, rb0);
+                if (t + 2 < nt) sstore(0, ra0, rb0, 0);
                 __syncthreads();
             }
         }
     } else {
         if (nt > 0) {
-            gload(kbeg, ra0, rb0);
+            // Regular K-tiles: full BK columns, no diagonal block of a triangular operand, vector-loadable.  They form one
+            // contiguous range [r0, r1) (diagonal blocks sit at one end of the K range, a ragged tile at the end).  The hot
+            // loop runs the tiles t of [r0, r1 - 1): tile t itself AND the tile t + 1 it stages are regular, so its body has
+            // no branch at all -- bare vector loads, every MFMA, every staging store.  With the choice between loader paths /
+            // MFMA masks inside ONE loop hipcc carried the accumulators and the staging registers through phi copies (two
+            // register sets, 64 v_mov per K-tile, spills inside the loop).
+            auto regular = [&](int t) __attribute__((always_inline)) {
+                const int64_t k0 = kbeg + (int64_t)t * BK;
+                if (k0 + BK > kend) return false;
+                if ((aL || aU) && (k0 < m0 + BM) && (k0 + BK > m0)) return false;
+                if ((bL || bU) && (k0 < n0 + BN) && (k0 + BK > n0)) return false;
+                return true;
+            };
+            int r0 = 0, r1 = 0;
+            if (EDGE == 0 && !cL_partial) {
+                while (r0 < nt && !regular(r0)) ++r0;
+                r1 = r0;
+                while (r1 < nt && regular(r1)) ++r1;
+            }
+#ifdef NSGP_GEMM_ONE_LOOP
+            const int h0 = 0, h1 = (EDGE == 0 && !cL_partial) ? nt - 1 : 0;
+#else
+            const int h0 = r0, h1 = r1 - 1 > r0 ? r1 - 1 : r0;             // hot range [h0, h1)
+#endif
+            auto generic_tiles = [&](int tb, int te) __attribute__((always_inline)) {
+                for (int t = tb; t < te; ++t) {
+                    const int buf = t & 1;
+                    const bool more = t + 1 < nt;
+                    if (more) gload(t + 1, ra0, rb0);                      // next tile -> registers (in flight)
+                    const int mk = __builtin_amdgcn_readfirstlane(tile_mask(kbeg + (int64_t)t * BK));
+                    // Two specialisations only -- all MFMA tiles, or none: a partly needed K-tile runs the full set (the
+                    // skipped MFMA tiles only ever multiply the zeros the loader wrote).
+                    if (mk == 0) ktile(buf, more, std::integral_constant<int, 0>{}, std::true_type{}, ra0, rb0);
+                    else ktile(buf, more, std::integral_constant<int, FULLMASK>{}, std::true_type{}, ra0, rb0);
+                    __syncthreads();
+                }
+            };
+            gload(0, ra0, rb0);
             sstore(0, ra0, rb0);
             __syncthreads();
-            for (int64_t t = 0; t < nt; ++t) {
-                const int buf = (int)(t & 1);
-                if (t + 1 < nt) gload(kbeg + (t + 1) * BK, ra0, rb0);      // next tile -> registers (in flight)
-                compute(buf);
-                if (t + 1 < nt) sstore(buf ^ 1, ra0, rb0);
-                __syncthreads();
+            generic_tiles(0, h0);
+            if (h1 > h0) {
+                const T* pa = la.cur + (int64_t)(h0 + 1) * BK * la.kstep;
+                const T* pb = lb.cur + (int64_t)(h0 + 1) * BK * lb.kstep;
+                const int64_t da = (int64_t)BK * la.kstep, db = (int64_t)BK * lb.kstep;
+                for (int t = h0; t < h1; ++t) {
+#pragma unroll
+                    for (int p = 0; p < PA; ++p) ra0[p] = ldg4(pa + p * la.pstep);
+#pragma unroll
+                    for (int p = 0; p < PB; ++p) rb0[p] = ldg4(pb + p * lb.pstep);
+                    if constexpr (KSC != 0) load_ks(kbeg + (int64_t)(t + 1) * BK);
+                    pa += da; pb += db;
+#ifdef NSGP_GEMM_ONE_LOOP
+                    {   // every tile through this loop: masks always applied, branch-free (a sentinel offset makes them
+                        // no-ops off the diagonal blocks)
+                        const int64_t k1 = kbeg + (int64_t)(t + 1) * BK;
+                        const bool ad = (aL || aU) && (k1 < m0 + BM) && (k1 + BK > m0);
+                        const bool bd = (bL || bU) && (k1 < n0 + BN) && (k1 + BK > n0);
+                        st_adiag[0] = aL || aU; st_bdiag[0] = bL || bU;
+                        st_ad[0] = ad ? (int)(k1 - m0) : (aL ? -(1 << 20) : (1 << 20));
+                        st_bd[0] = bd ? (int)(k1 - n0) : (bU ? -(1 << 20) : (1 << 20));
+                    }
+                    ktile(t & 1, true, std::integral_constant<int, FULLMASK>{}, std::true_type{}, ra0, rb0);
+#else
+                    ktile(t & 1, true, std::integral_constant<int, FULLMASK>{}, std::false_type{}, ra0, rb0);
+#endif
+                    __syncthreads();
+                }
             }
+            generic_tiles(h1 > h0 ? h1 : h0, nt);
         }
     }
 
@@ -612,84 +785,100 @@ int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam,
                 if (e != hipSuccess) return (int)e;
             }
     }
-    dim3 grid((unsigned)ngrid, (unsigned)(nb * g.ksplit), 1);
+    int64_t ngrid_x = ngrid, ngrid_y = nb * g.ksplit;
+    g.xcd_group = 0;
+    g.xcd_chunk = 0;
+    g.nbk = (int)(nb * g.ksplit);
+    const char* no_xcd = getenv("NSGP_GEMM_NO_XCD");              // A/B switches for tools/gemm_bench.py
+    const bool xcd_ok = !(no_xcd && no_xcd[0] == '1');
+    // The column-panel-grouped order is OFF by default: it cuts the fabric traffic of the projections ~3x, but the
+    // hardware deals workgroups to the XCDs in strict rotation, so tiles of unequal length in flight stall the
+    // dispatcher (measured: 611 us grouped vs 472 us in the row-major longest-first order, M=1024, n=40960).
+    const char* grp = getenv("NSGP_GEMM_XCD_GROUP");
+    const bool group_ok = grp && grp[0] == '1';
+    if (xcd_ok && group_ok && !(flags & NSGP_GEMM_C_LOWER) && g.ksplit == 1 && g.tiles_n >= 16 && g.tiles_m <= 64 &&
+        !(flags & (NSGP_GEMM_B_LOWER | NSGP_GEMM_B_UPPER))) {
+        const bool triA = flags & (NSGP_GEMM_A_LOWER | NSGP_GEMM_A_UPPER);
+        int R = (int)g.tiles_m;
+        if (triA && g.tiles_m >= 4 && g.tiles_m % 2 == 0) R = (int)g.tiles_m / 2;     // long rows first, short rows last
+        g.xcd_group = R;
+        ngrid_x = 8 * (g.tiles_m / R) * (cdiv64(g.tiles_n, 8) * R);
+    } else if (xcd_ok && g.ksplit > 1 && ngrid * ngrid_y >= 64) {
+        const int64_t total = ngrid * ngrid_y;
+        g.xcd_chunk = (int)cdiv64(total, 8);
+        // the launch keeps its (tiles, batch x slices) shape; workgroups past `total` after the remap exit at once
+        ngrid_y = cdiv64(8 * (int64_t)g.xcd_chunk, ngrid);
+    }
+    dim3 grid((unsigned)ngrid_x, (unsigned)ngrid_y, 1);
     Epi ep{};
     if (epi) ep = *epi;
     if (tiles_m_out) *tiles_m_out = g.tiles_m;
     const int ekind = ep.kind, eks = ep.ks != nullptr;
     const bool one_round = ngrid * nb * g.ksplit <= 256 * 3;      // f64: latency-bound single-round grids take PF = 1
     if (ekind != 0 && (g.ksplit != 1 || beta != T(0) || (flags & NSGP_GEMM_C_LOWER))) return -30;
-#define NSGP_LAUNCH_X(BMN, MA, MB, EP, KS) NSGP_LAUNCH_XY(BMN, BMN, MA, MB, EP, KS)
-#define NSGP_LAUNCH_XY(BM_, BN_, MA, MB, EP, KS)                                                          \
-    do {                                                                                                  \
-        constexpr int BKc = (BM_ == 128 ? 32 : 16);                                                       \
-        constexpr int pa = (MA == 0 && sizeof(T) == 4) ? 1 : Mfma<T>::PAD;                                \
-        constexpr int pb = (MB == 0 && sizeof(T) == 4) ? 1 : Mfma<T>::PAD;                                \
-        constexpr size_t lds = 2 * BKc * ((BM_ + pa) + (BN_ + pb)) * sizeof(T);                           \
-        auto kern = gemm_kernel<T, BM_, BN_, BKc, MA, MB, EP, KS>;                                        \
-        nsgp_opt_in_lds((const void*)kern, lds);                                                          \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g, alpha, A, B, beta, C, slabs, ep);           \
-    } while (0)
-#define NSGP_LAUNCH_EPI(BMN)                                                                              \
-    do {                                                                                                  \
-        if (ekind == 1 && !eks && g.modeA == 0 && g.modeB == 1) NSGP_LAUNCH_X(BMN, 0, 1, 1, 0);           \
-        else if (ekind == 1 && !eks && g.modeA == 1 && g.modeB == 1) NSGP_LAUNCH_X(BMN, 1, 1, 1, 0);      \
-        else if (ekind == 2 && !eks && g.modeA == 0 && g.modeB == 1) NSGP_LAUNCH_X(BMN, 0, 1, 2, 0);      \
-        else if (ekind == 0 && eks && g.modeA == 0 && g.modeB == 0) NSGP_LAUNCH_X(BMN, 0, 0, 0, 1);       \
-        else return -31;                                                                                  \
-    } while (0)
+    const int64_t bnn = p.narrow ? 64 : bmn, bkk = (bmn == 128 ? 32 : 16);
+    // whole, vector-loadable tiles everywhere -> the variant without bounds code (EDGE = 0)
+    const bool whole = g.vecA && g.vecB && M % bmn == 0 && N % bnn == 0 && K % bkk == 0 && g.kper % bkk == 0;
+    // launch<BM, BN, MA, MB, EP, KS>(): the PF = 1 variant only exists for plain float64 kernels
+    auto launch = [&](auto bm_c, auto bn_c, auto ma_c, auto mb_c, auto ep_c, auto ks_c) {
+        constexpr int BM_ = decltype(bm_c)::value, BN_ = decltype(bn_c)::value, MA = decltype(ma_c)::value,
+                      MB = decltype(mb_c)::value, EP = decltype(ep_c)::value, KSv = decltype(ks_c)::value;
+        constexpr int BKc = (BM_ == 128 ? 32 : 16);
+        constexpr int pa = (MA == 0 && sizeof(T) == 4) ? 1 : Mfma<T>::PAD;
+        constexpr int pb = (MB == 0 && sizeof(T) == 4) ? 1 : Mfma<T>::PAD;
+        constexpr size_t lds = 2 * BKc * ((BM_ + pa) + (BN_ + pb)) * sizeof(T);
+        auto go = [&](auto kern) {
+            nsgp_opt_in_lds((const void*)kern, lds);
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g, alpha, A, B, beta, C, slabs, ep);
+        };
+        if constexpr (sizeof(T) == 8 && EP == 0 && KSv == 0 && BM_ == 64) {
+            if (one_round) {
+                if (whole) go(gemm_kernel<T, BM_, BN_, BKc, MA, MB, 0, 0, 1, 0>);
+                else go(gemm_kernel<T, BM_, BN_, BKc, MA, MB, 0, 0, 1, 1>);
+                return;
+            }
+        }
+        if (whole) go(gemm_kernel<T, BM_, BN_, BKc, MA, MB, EP, KSv, 0, 0>);
+        else go(gemm_kernel<T, BM_, BN_, BKc, MA, MB, EP, KSv, 0, 1>);
+    };
+#define IC(v) std::integral_constant<int, v>{}
+    // fused variants exist for the operand layouts the SVGP layer uses
+    auto launch_epi = [&](auto bm_c, auto bn_c) -> int {
+        if (ekind == 1 && !eks && g.modeA == 0 && g.modeB == 1) launch(bm_c, bn_c, IC(0), IC(1), IC(1), IC(0));
+        else if (ekind == 1 && !eks && g.modeA == 1 && g.modeB == 1) launch(bm_c, bn_c, IC(1), IC(1), IC(1), IC(0));
+        else if (ekind == 2 && !eks && g.modeA == 0 && g.modeB == 1) launch(bm_c, bn_c, IC(0), IC(1), IC(2), IC(0));
+        else if (ekind == 0 && eks && g.modeA == 0 && g.modeB == 0) launch(bm_c, bn_c, IC(0), IC(0), IC(0), IC(1));
+        else return -31;
+        return 0;
+    };
+    auto launch_plain = [&](auto bm_c, auto bn_c) {
+        if (g.modeA == 0 && g.modeB == 0) launch(bm_c, bn_c, IC(0), IC(0), IC(0), IC(0));
+        else if (g.modeA == 0) launch(bm_c, bn_c, IC(0), IC(1), IC(0), IC(0));
+        else if (g.modeB == 0) launch(bm_c, bn_c, IC(1), IC(0), IC(0), IC(0));
+        else launch(bm_c, bn_c, IC(1), IC(1), IC(0), IC(0));
+    };
+    int lrc = 0;
     if (p.narrow) {
         if constexpr (sizeof(T) == 4) {
             if (eks) return -31;
-            if (ekind == 1 && g.modeA == 0 && g.modeB == 1) NSGP_LAUNCH_XY(128, 64, 0, 1, 1, 0);
-            else if (ekind == 1 && g.modeA == 1 && g.modeB == 1) NSGP_LAUNCH_XY(128, 64, 1, 1, 1, 0);
-            else if (ekind == 2 && g.modeA == 0 && g.modeB == 1) NSGP_LAUNCH_XY(128, 64, 0, 1, 2, 0);
-            else if (ekind != 0) return -31;
-            else if (g.modeA == 0 && g.modeB == 0) NSGP_LAUNCH_XY(128, 64, 0, 0, 0, 0);
-            else if (g.modeA == 0) NSGP_LAUNCH_XY(128, 64, 0, 1, 0, 0);
-            else if (g.modeB == 0) NSGP_LAUNCH_XY(128, 64, 1, 0, 0, 0);
-            else NSGP_LAUNCH_XY(128, 64, 1, 1, 0, 0);
+            if (ekind != 0) lrc = launch_epi(IC(128), IC(64));
+            else launch_plain(IC(128), IC(64));
         }
     } else if (ekind != 0 || eks) {
         if (p.big) {
-            if constexpr (sizeof(T) == 4) NSGP_LAUNCH_EPI(128);
+            if constexpr (sizeof(T) == 4) lrc = launch_epi(IC(128), IC(128));
         } else {
-            NSGP_LAUNCH_EPI(64);
+            lrc = launch_epi(IC(64), IC(64));
         }
     } else {
-#define NSGP_LAUNCH(BMN, MA, MB)                                                                          \
-    do {                                                                                                  \
-        constexpr int BKc = (BMN == 128 && sizeof(T) == 4 ? 32 : 16);                                                     \
-        constexpr int pa = (MA == 0 && sizeof(T) == 4) ? 1 : Mfma<T>::PAD;                                \
-        constexpr int pb = (MB == 0 && sizeof(T) == 4) ? 1 : Mfma<T>::PAD;                                \
-        constexpr size_t lds = 2 * BKc * ((BMN + pa) + (BMN + pb)) * sizeof(T);                           \
-        if (sizeof(T) == 8 && one_round) {                                                                \
-            hipLaunchKernelGGL((gemm_kernel<T, BMN, BMN, BKc, MA, MB, 0, 0, (sizeof(T) == 8 ? 1 : 0)>), grid,   \
-                               dim3(256), lds, st, g, alpha, A, B, beta, C, slabs, ep);                   \
-            break;                                                                                        \
-        }                                                                                                 \
-        auto kern = gemm_kernel<T, BMN, BMN, BKc, MA, MB>;                                                \
-        nsgp_opt_in_lds((const void*)kern, lds);                                                          \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g, alpha, A, B, beta, C, slabs, ep);           \
-    } while (0)
-#define NSGP_LAUNCH_MODES(BMN)                                                 \
-    do {                                                                       \
-        if (g.modeA == 0 && g.modeB == 0) NSGP_LAUNCH(BMN, 0, 0);              \
-        else if (g.modeA == 0) NSGP_LAUNCH(BMN, 0, 1);                         \
-        else if (g.modeB == 0) NSGP_LAUNCH(BMN, 1, 0);                         \
-        else NSGP_LAUNCH(BMN, 1, 1);                                           \
-    } while (0)
-    if (p.big) {
-        if constexpr (sizeof(T) == 4) NSGP_LAUNCH_MODES(128);
-    } else {
-        NSGP_LAUNCH_MODES(64);
+        if (p.big) {
+            if constexpr (sizeof(T) == 4) launch_plain(IC(128), IC(128));
+        } else {
+            launch_plain(IC(64), IC(64));
+        }
     }
-#undef NSGP_LAUNCH_MODES
-#undef NSGP_LAUNCH
-    }
-#undef NSGP_LAUNCH_EPI
-#undef NSGP_LAUNCH_X
-#undef NSGP_LAUNCH_XY
+#undef IC
+    if (lrc != 0) return lrc;
     if (g.ksplit > 1) {
         const int64_t tot = nb * M * N;
         hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, st, g, alpha,

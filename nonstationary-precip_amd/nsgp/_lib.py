@@ -11,7 +11,8 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
 HEADER = os.path.join(_ROOT, 'include', 'nsgp.h')
-LIB_PATH = os.path.join(_HERE, 'libnsgp_hip.so')
+# NSGP_LIB: developer hook for A/B timing of an experimental build of the SAME library (tools/gemm_bench.py)
+LIB_PATH = os.environ.get('NSGP_LIB') or os.path.join(_HERE, 'libnsgp_hip.so')
 
 
 class BackendError(RuntimeError):

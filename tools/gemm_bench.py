@@ -1,68 +1,65 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of the MFMA GEMM on the six (M x M x n) products of one SVGP layer step
-(BASELINE B4 last layer: M=1024, n=S*B=40960).  Prints TFLOP/s (algorithmic: triangular halves)."""
+"""Micro-benchmark of the MFMA GEMM on the (M x M x n) products of one SVGP layer step (BASELINE B4: M=1024;
+last layer n = S*B = 40960, one GP; hidden layer n = 4096, two GPs).  Interleaved rounds in ONE process
+(cdna_hip_programming.md rule 24): every case runs once per round, ROUNDS rounds; prints the median and the minimum
+time and the TFLOP/s of the median (algorithmic flops: triangular halves counted once).
+
+    python tools/gemm_bench.py                 # last-layer shapes
+    NCOLS=4096 BATCH=2 python tools/gemm_bench.py
+    ENVAB=NSGP_GEMM_XCD_GROUP python tools/gemm_bench.py     # A/B an environment switch of the library (0 / 1)
+"""
 import os
 import sys
-import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'nonstationary-precip_amd'))
 import torch  # noqa: E402
 from nsgp import ops  # noqa: E402
 
-M, n = 1024, int(os.environ.get('NCOLS', 40960))
-reps = int(os.environ.get('REPS', 10))
-dt = torch.float32
+M, n = int(os.environ.get('MROWS', 1024)), int(os.environ.get('NCOLS', 40960))
+b = int(os.environ.get('BATCH', 1))
+rounds = int(os.environ.get('ROUNDS', 15))
 g = torch.Generator().manual_seed(0)
-W = torch.tril(torch.randn(M, M, generator=g)).cuda()
-Lq = torch.tril(torch.randn(M, M, generator=g)).cuda()
-PAD = int(os.environ.get('PAD', 0))
-
-
-def padded(t):
-    if not PAD:
-        return t.cuda()
-    buf = torch.empty(t.shape[0], t.shape[1] + PAD, device='cuda')
-    v = buf[:, :t.shape[1]]
-    v.copy_(t)
-    return v
-
-
-K = padded(torch.randn(M, n, generator=g))
-A = padded(torch.randn(M, n, generator=g))
-W = padded(W.cpu())
-Lq = padded(Lq.cpu())
-out = torch.empty(M, n, device='cuda')
-Bt = torch.randn(n, M, generator=g).cuda()
-At = torch.randn(n, M, generator=g).cuda()
-print('PAD', PAD, 'strides', K.stride(), W.stride())
+W = torch.tril(torch.randn(b, M, M, generator=g)).cuda()
+Lq = torch.tril(torch.randn(b, M, M, generator=g)).cuda()
+K = torch.randn(b, M, n, generator=g).cuda()
+A = torch.randn(b, M, n, generator=g).cuda()
+m = torch.randn(b, M, generator=g).cuda()
+gm, gv = torch.randn(b, n, generator=g).cuda(), torch.randn(b, n, generator=g).cuda()
+os_ = torch.ones(b).cuda()
+Cc = torch.randn(b, M, n, generator=g).cuda()
+tri = M * M * n * b
 
 cases = [
-    ('A=W K      NN  A_LOWER', lambda: ops.gemm(W, K, flags=ops.GEMM_A_LOWER), M * M * n),
-    ('C=Lq^T A   TN  A_UPPER', lambda: ops.gemm(Lq, A, ta=True, flags=ops.GEMM_A_UPPER), M * M * n),
-    ('Ab+=Lq C2  NN  beta=1 ', lambda: ops.gemm(Lq, K, flags=ops.GEMM_A_LOWER, beta=1.0, out=out), M * M * n),
-    ('Lqb=A C2^T NT  C_LOWER', lambda: ops.gemm(A, K, tb=True, flags=ops.GEMM_C_LOWER), M * M * n),
-    ('Kb=W^T Ab  TN  A_UPPER', lambda: ops.gemm(W, A, ta=True, flags=ops.GEMM_A_UPPER), M * M * n),
-    ('plain NN   full       ', lambda: ops.gemm(W, K), 2 * M * M * n),
-    ('NT wide  W * Bt^T full', lambda: ops.gemm(W, Bt, tb=True), 2 * M * M * n),
-    ('TT? no: TN wide full  ', lambda: ops.gemm(W, K, ta=True), 2 * M * M * n),
-    ('NT long-K full nosplit', lambda: ops.gemm(A, K, tb=True, flags=ops.GEMM_NO_SPLITK), 2 * M * M * n),
-    ('NT long-K full split  ', lambda: ops.gemm(A, K, tb=True), 2 * M * M * n),
-    ('TN long-K full (k-maj)', lambda: ops.gemm(At, Bt, ta=True), 2 * M * M * n),
-    ('TN long-K C_LOWER kmaj', lambda: ops.gemm(At, Bt, ta=True, flags=ops.GEMM_C_LOWER), M * M * n),
-    ('transpose M x n -> n x M', lambda: A.t().contiguous(), 0),
+    ('fwd  A=W K, C=Lq^T A (+colstats)', lambda: ops.svgp_project(W, K, Lq, m, os_), 2 * tri),
+    ('bwd  Abar (epi 2) + Lqbar (ksc)  ', lambda: ops.svgp_project_bwd(Lq, m, A, Cc, gm, gv), 2 * tri),
+    ('bwd  Kzxbar = W^T Abar  A_UPPER  ', lambda: ops.gemm(W, A, ta=True, flags=ops.GEMM_A_UPPER), tri),
+    ('bwd  Wbar = tril(Abar Kzx^T)     ', lambda: ops.gemm(A, K, tb=True, flags=ops.GEMM_C_LOWER), tri),
+    ('     A=W K   A_LOWER plain       ', lambda: ops.gemm(W, K, flags=ops.GEMM_A_LOWER), tri),
+    ('     dense NN (full W)           ', lambda: ops.gemm(W, K), 2 * tri),
+    ('     dense NT long-K, split      ', lambda: ops.gemm(A, K, tb=True), 2 * tri),
 ]
 only = os.environ.get('ONLY')
+if only:
+    cases = [c for c in cases if only in c[0]]
+envab = os.environ.get('ENVAB')
+variants = [('', None)] if not envab else [(f' [{envab}=0]', '0'), (f' [{envab}=1]', '1')]
+times = {(c[0], v[0]): [] for c in cases for v in variants}
+for r in range(rounds + 2):
+    for name, fn, flops in cases:
+        for tag, val in variants:
+            if val is not None:
+                os.environ[envab] = val
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            if r >= 2:
+                times[(name, tag)].append(e0.elapsed_time(e1))
+print(f'M={M} n={n} batch={b} rounds={rounds}')
 for name, fn, flops in cases:
-    if only is not None and only not in name:
-        continue
-    fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    print(f'{name}: {ms*1e3:8.1f} us  {flops/ms/1e9:7.1f} TFLOP/s', flush=True)
+    for tag, _ in variants:
+        t = sorted(times[(name, tag)])
+        med, mn = t[len(t) // 2], t[0]
+        print(f'{name}{tag}: median {med * 1e3:8.1f} us  min {mn * 1e3:8.1f} us  {flops / med / 1e9:7.1f} TFLOP/s', flush=True)
