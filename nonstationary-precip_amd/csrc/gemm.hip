@@ -494,11 +494,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64) ? 3 : 2) void gemm_ker
                 r1 = r0;
                 while (r1 < nt && regular(r1)) ++r1;
             }
-#ifdef NSGP_GEMM_ONE_LOOP
-            const int h0 = 0, h1 = (EDGE == 0 && !cL_partial) ? nt - 1 : 0;
-#else
             const int h0 = r0, h1 = r1 - 1 > r0 ? r1 - 1 : r0;             // hot range [h0, h1)
-#endif
             auto generic_tiles = [&](int tb, int te) __attribute__((always_inline)) {
                 for (int t = tb; t < te; ++t) {
                     const int buf = t & 1;
@@ -527,20 +523,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64) ? 3 : 2) void gemm_ker
                     for (int p = 0; p < PB; ++p) rb0[p] = ldg4(pb + p * lb.pstep);
                     if constexpr (KSC != 0) load_ks(kbeg + (int64_t)(t + 1) * BK);
                     pa += da; pb += db;
-#ifdef NSGP_GEMM_ONE_LOOP
-                    {   // every tile through this loop: masks always applied, branch-free (a sentinel offset makes them
-                        // no-ops off the diagonal blocks)
-                        const int64_t k1 = kbeg + (int64_t)(t + 1) * BK;
-                        const bool ad = (aL || aU) && (k1 < m0 + BM) && (k1 + BK > m0);
-                        const bool bd = (bL || bU) && (k1 < n0 + BN) && (k1 + BK > n0);
-                        st_adiag[0] = aL || aU; st_bdiag[0] = bL || bU;
-                        st_ad[0] = ad ? (int)(k1 - m0) : (aL ? -(1 << 20) : (1 << 20));
-                        st_bd[0] = bd ? (int)(k1 - n0) : (bU ? -(1 << 20) : (1 << 20));
-                    }
-                    ktile(t & 1, true, std::integral_constant<int, FULLMASK>{}, std::true_type{}, ra0, rb0);
-#else
                     ktile(t & 1, true, std::integral_constant<int, FULLMASK>{}, std::false_type{}, ra0, rb0);
-#endif
                     __syncthreads();
                 }
             }
