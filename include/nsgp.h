@@ -231,6 +231,16 @@ int nsgp_svgp_tri_gemm_colstats_f32(const float* L, int trans, const float* X, c
 int nsgp_svgp_tri_gemm_colstats_f64(const double* L, int trans, const double* X, const double* rowvec, int64_t batch,
                                     int64_t M, int64_t n, double* Y, double* part_dot, double* part_sq,
                                     void* stream);
+/* The whitened projection A = L^-1 Kzx with float64 arithmetic on float32 data: Y[b] = W[b] X[b], W float64 lower
+ * triangular (= chol(Kzz)^-1), X / Y / rowvec / partials float32; float64 MFMA accumulation.  This is what the
+ * reference computes -- gpytorch VariationalStrategy.forward solves L A = Kzx.double() and casts A back (SURVEY A.3;
+ * driven by /root/reference/models/dgps.py:48-51) -- where a float32 product W Kzx loses 2e-4 at kappa(Kzz) ~ 1e6.
+ * The kernel fills ceil(M / 128) tile rows (nsgp_svgp_f64acc_tiles) of partial buffers laid out with `part_rows`
+ * (>= that number) tile rows per batch element; the caller zeroes the rows it does not fill. */
+size_t nsgp_svgp_f64acc_tiles(int64_t M);
+int nsgp_svgp_tri_gemm_colstats_f64acc(const double* W, const float* X, const float* rowvec, int64_t batch, int64_t M,
+                                       int64_t n, float* Y, float* part_dot, float* part_sq, int64_t part_rows,
+                                       void* stream);
 int nsgp_svgp_colstats_finalize_f32(const float* part_dot, const float* part_sq_a, const float* part_sq_c,
                                     const float* base, int64_t batch, int64_t tiles, int64_t n, float* mean,
                                     float* var, void* stream);

@@ -60,6 +60,7 @@ struct GemmArgs {
     int64_t slab;                 // elements per (slice) slab = nb1*nb2*M*N when ksplit > 1
     int flags;
     int nbk;                      // batch x K-slices (the logical extent of grid.y)
+    int part_rows;                // EPI 1: tile rows per batch element in the partial buffers (>= tiles_m; 0 = tiles_m)
     int xcd_chunk;                // > 0: chunked XCD placement of a split-K launch, workgroups per XCD (see the kernel)
     int xcd_group;                // > 0: XCD-aware tile order with this many tile rows per group (see the kernel)
     int vecA, vecB;               // 16-byte vector global loads allowed for A / B
@@ -152,10 +153,19 @@ struct TileLoader {
 // MODE_A / MODE_B: 0 = operand contiguous along k, 1 = contiguous along m (n).
 // EDGE = 0: every tile of the launch is whole and vector-loadable (M % BM == N % BN == K % BK == 0, 16-byte aligned
 // operands: the host checks) -- no bounds code is compiled in; EDGE = 1: ragged / unaligned shapes, element-wise loads.
-template <typename T, int BM, int BN, int BK, int MODE_A, int MODE_B, int EPI = 0, int KSC = 0, int PF = 0, int EDGE = 1>
-__global__ __launch_bounds__(256, (BM == 128 && BN == 64) ? 3 : 2) void gemm_kernel(GemmArgs g, T alpha, const T* __restrict__ A,
+// MIX = 1 (T = double only): float64 arithmetic on float32 data -- the B operand, the output, the row vector and the
+// column-statistic partials are float32 in memory (pointers passed as T*, strides in elements); A and the MFMA
+// accumulation are float64.  This is the whitened projection A = L^-1 Kzx of the SVGP layer: the reference solves it
+// in float64 and rounds once; float32 accumulation of W Kzx loses 2e-4 at kappa(Kzz) ~ 1e6 (terms of size |W||K| ~ 80
+// cancel to O(1); tools/probes/whiten_precision.py), float64 accumulation reproduces the float64 solve to 3e-8.
+template <typename T, int BM, int BN, int BK, int MODE_A, int MODE_B, int EPI = 0, int KSC = 0, int PF = 0, int EDGE = 1,
+          int MIX = 0>
+__global__ __launch_bounds__(256, (BM == 128 && BN == 64 && sizeof(T) == 4) ? 3 : 2) void gemm_kernel(GemmArgs g, T alpha, const T* __restrict__ A,
                                                    const T* __restrict__ B, T beta, T* __restrict__ C,
                                                    T* __restrict__ slabs, Epi ep) {
+    static_assert(MIX == 0 || (sizeof(T) == 8 && EPI == 1 && KSC == 0 && PF == 0), "MIX: float64 colstats projection only");
+    using TB = std::conditional_t<MIX != 0, float, T>;          // element type of B in memory
+    using TC = std::conditional_t<MIX != 0, float, T>;          // element type of C / rv / partials in memory
     using MF = Mfma<T>;
     constexpr int MT = MF::MT, KS = MF::KS, NKK = BK / KS;
     constexpr int KCH = NKK < 8 ? NKK : 8;                      // k-steps whose fragments are prefetched together (PF2)
@@ -235,8 +245,8 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64) ? 3 : 2) void gemm_ker
     const int64_t m0 = (int64_t)bm * BM, n0 = (int64_t)bn * BN;
 
     const T* Ab = A + b1 * g.sa1 + b2 * g.sa2;
-    const T* Bb = B + b1 * g.sb1 + b2 * g.sb2;
-    T* Cb = C + b1 * g.sc1 + b2 * g.sc2;
+    const TB* Bb = reinterpret_cast<const TB*>(B) + b1 * g.sb1 + b2 * g.sb2;
+    TC* Cb = reinterpret_cast<TC*>(C) + b1 * g.sc1 + b2 * g.sc2;
 
     const bool aL = g.flags & NSGP_GEMM_A_LOWER, aU = g.flags & NSGP_GEMM_A_UPPER;
     const bool bL = g.flags & NSGP_GEMM_B_LOWER, bU = g.flags & NSGP_GEMM_B_UPPER;
@@ -261,7 +271,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64) ? 3 : 2) void gemm_ker
             for (int r = 0; r < MF::NREG; ++r) acc[i][j][r] = T(0);
 
     TileLoader<T, MODE_A, BM, BK, PA> la;
-    TileLoader<T, MODE_B, BN, BK, PB> lb;
+    TileLoader<TB, MODE_B, BN, BK, PB> lb;
     la.init(tid, Ab, m0, g.sam, g.sak, kbeg);
     lb.init(tid, Bb, n0, g.sbn, g.sbk, kbeg);
     const int mrem = (int)(g.M - m0 < BM ? g.M - m0 : BM), nrem = (int)(g.N - n0 < BN ? g.N - n0 : BN);
@@ -271,7 +281,8 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64) ? 3 : 2) void gemm_ker
     // register sets.  It costs a wave of occupancy (3 -> 2 per SIMD), which multi-round grids need more
     // (N=16384 potrf: 39 ms without, 51 ms with), so those keep PF = 0.
     constexpr bool PF2 = PF != 0 && sizeof(T) == 8 && KSC == 0;
-    Frag4<T> ra0[PA], rb0[PB], ra1[PF2 ? PA : 1], rb1[PF2 ? PB : 1];
+    Frag4<T> ra0[PA], ra1[PF2 ? PA : 1];
+    Frag4<TB> rb0[PB], rb1[PF2 ? PB : 1];
     Frag4<T> rks[KSC ? PB : 1];
     const T* ksb = KSC ? reinterpret_cast<const T*>(ep.ks) + bb * g.K : nullptr;
     const bool ks_vec = KSC && ((uintptr_t)ksb % (4 * sizeof(T)) == 0);
@@ -298,7 +309,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64) ? 3 : 2) void gemm_ker
             }
         }
     };
-    auto gload = [&](int t, Frag4<T>* ra, Frag4<T>* rb, int set = 0) __attribute__((always_inline)) {
+    auto gload = [&](int t, Frag4<T>* ra, Frag4<TB>* rb, int set = 0) __attribute__((always_inline)) {
         const int64_t k0 = kbeg + (int64_t)t * BK;
         if constexpr (EDGE == 0) {
             la.load_fast(ra, (int64_t)t * BK);
@@ -319,7 +330,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64) ? 3 : 2) void gemm_ker
     };
     // one four-element piece of the staged tile -> LDS (k-major images As[k][m], Bs[k][n])
     constexpr int NPIECE = PA + PB;
-    auto store_piece = [&](int buf, int q, Frag4<T>* ra, Frag4<T>* rb, auto masked_c, int set = 0) __attribute__((always_inline)) {
+    auto store_piece = [&](int buf, int q, Frag4<T>* ra, Frag4<TB>* rb, auto masked_c, int set = 0) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_c)::value;
         if (q < PA) {
             const int p = q;
@@ -336,14 +347,14 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64) ? 3 : 2) void gemm_ker
             }
             if constexpr (KSC != 0) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) rb[p].v[e] *= (MODE_B == 0 ? rks[0].v[e] : rks[p].v[0]);
+                for (int e = 0; e < 4; ++e) rb[p].v[e] *= (TB)(MODE_B == 0 ? rks[0].v[e] : rks[p].v[0]);
             }
             T* dst = &Bs[buf][lb.pk(p) * LDB + lb.prow(p)];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dst[MODE_B == 0 ? e * LDB : e] = rb[p].v[e];
+            for (int e = 0; e < 4; ++e) dst[MODE_B == 0 ? e * LDB : e] = (T)rb[p].v[e];
         }
     };
-    auto sstore = [&](int buf, Frag4<T>* ra, Frag4<T>* rb, int set = 0) __attribute__((always_inline)) {
+    auto sstore = [&](int buf, Frag4<T>* ra, Frag4<TB>* rb, int set = 0) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < NPIECE; ++q) store_piece(buf, q, ra, rb, std::true_type{}, set);
     };
@@ -386,7 +397,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64) ? 3 : 2) void gemm_ker
     constexpr int KS0 = NKK / 2;                                     // first k-step that carries staging stores
     constexpr int PPS = (NPIECE + (NKK - KS0) - 1) / (NKK - KS0);    // pieces per k-step
     constexpr int FULLMASK = (1 << (TM * TN)) - 1;
-    auto ktile = [&](int buf, bool stage, auto tmask_c, auto masked_c, Frag4<T>* ra, Frag4<T>* rb) __attribute__((always_inline)) {
+    auto ktile = [&](int buf, bool stage, auto tmask_c, auto masked_c, Frag4<T>* ra, Frag4<TB>* rb) __attribute__((always_inline)) {
         constexpr int tmask = decltype(tmask_c)::value;          // compile-time: a runtime mask makes every MFMA conditional
         const T* as = &As[buf][kr * LDA + wm0 + mc];             // and hipcc then keeps two copies of the accumulators
         const T* bs = &Bs[buf][kr * LDB + wn0 + mc];
@@ -514,7 +525,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64) ? 3 : 2) void gemm_ker
             generic_tiles(0, h0);
             if (h1 > h0) {
                 const T* pa = la.cur + (int64_t)(h0 + 1) * BK * la.kstep;
-                const T* pb = lb.cur + (int64_t)(h0 + 1) * BK * lb.kstep;
+                const TB* pb = lb.cur + (int64_t)(h0 + 1) * BK * lb.kstep;
                 const int64_t da = (int64_t)BK * la.kstep, db = (int64_t)BK * lb.kstep;
                 for (int t = h0; t < h1; ++t) {
 #pragma unroll
@@ -534,7 +545,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64) ? 3 : 2) void gemm_ker
     // epilogue
     if constexpr (EPI == 1) {
         // plain store + per-column partial sums over this tile's rows (rows >= M carry acc == 0)
-        const T* rv = ep.rv ? reinterpret_cast<const T*>(ep.rv) + bb * g.M : nullptr;
+        const TC* rv = ep.rv ? reinterpret_cast<const TC*>(ep.rv) + bb * g.M : nullptr;
         T sdot[TN], ssq[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) { sdot[j] = T(0); ssq[j] = T(0); }
@@ -543,12 +554,12 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64) ? 3 : 2) void gemm_ker
 #pragma unroll
             for (int r = 0; r < MF::NREG; ++r) {
                 const int64_t row = m0 + wm0 + i * MT + MF::crow(r, lane);
-                const T rvv = (rv && row < g.M) ? rv[row] : T(0);
+                const T rvv = (rv && row < g.M) ? (T)rv[row] : T(0);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int64_t col = n0 + wn0 + j * MT + MF::ccol(lane);
                     const T v = alpha * acc[i][j][r];
-                    if (row < g.M && col < g.N) Cb[row * g.ldc + col] = v;
+                    if (row < g.M && col < g.N) Cb[row * g.ldc + col] = (TC)v;
                     sdot[j] += v * rvv;
                     ssq[j] += v * v;
                 }
@@ -574,9 +585,9 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64) ? 3 : 2) void gemm_ker
         }
         __syncthreads();
         if (tid < BN && n0 + tid < g.N) {
-            const int64_t o = (bb * g.tiles_m + bm) * g.N + n0 + tid;
-            if (ep.p0) reinterpret_cast<T*>(ep.p0)[o] = red[tid] + red[BN + tid];
-            reinterpret_cast<T*>(ep.p1)[o] = red[2 * BN + tid] + red[3 * BN + tid];
+            const int64_t o = (bb * (g.part_rows > 0 ? g.part_rows : g.tiles_m) + bm) * g.N + n0 + tid;
+            if (ep.p0) reinterpret_cast<TC*>(ep.p0)[o] = (TC)(red[tid] + red[BN + tid]);
+            reinterpret_cast<TC*>(ep.p1)[o] = (TC)(red[2 * BN + tid] + red[3 * BN + tid]);
         }
         return;
     } else if constexpr (EPI == 2) {
@@ -617,6 +628,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64) ? 3 : 2) void gemm_ker
         }
         return;
     }
+    if constexpr (MIX == 0) {
     const bool to_slab = g.ksplit > 1;
     T* out = to_slab ? slabs + slice * g.slab + bb * g.M * g.N : Cb;
     const int64_t ldo = to_slab ? g.N : g.ldc;
@@ -643,6 +655,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64) ? 3 : 2) void gemm_ker
                     }
                 }
             }
+    }   // MIX == 0
 }
 
 // C = alpha * sum_s slab[s] + beta * C   (fixed summation order)
@@ -771,6 +784,7 @@ int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam,
     int64_t ngrid_x = ngrid, ngrid_y = nb * g.ksplit;
     g.xcd_group = 0;
     g.xcd_chunk = 0;
+    g.part_rows = 0;
     g.nbk = (int)(nb * g.ksplit);
     const char* no_xcd = getenv("NSGP_GEMM_NO_XCD");              // A/B switches for tools/gemm_bench.py
     const bool xcd_ok = !(no_xcd && no_xcd[0] == '1');
@@ -911,7 +925,57 @@ int lqbar_impl(const T* A, const T* C, const T* gvar, int64_t batch, int64_t M, 
 }
 }  // namespace
 
+namespace {
+// A = L^-1-style projection with float64 arithmetic on float32 data (gemm_kernel<double, 128, 64, 16, ..., MIX = 1>):
+// Y[b] = W[b] X[b] (W: float64 lower triangular (M x M); X, Y: float32 (M x n)), plus the column-statistic partials of
+// nsgp_svgp_tri_gemm_colstats (float32; ceil(M / 128) tile rows).
+int tri_gemm_colstats_f64acc_impl(const double* W, const float* X, const float* rowvec, int64_t batch, int64_t M, int64_t n,
+                                  float* Y, float* part_dot, float* part_sq, int64_t part_rows, void* stream) {
+    if (!W) return -1; if (!X) return -2; if (batch < 0) return -4; if (M < 0) return -5; if (n < 0) return -6;
+    if (!Y) return -7; if (!part_sq) return -9;
+    if (batch == 0 || M == 0 || n == 0) return 0;
+    constexpr int BM_ = 128, BN_ = 64, BK_ = 16;
+    if (part_rows < cdiv64(M, BM_)) return -10;
+    GemmArgs g{};
+    g.M = M; g.N = n; g.K = M;
+    g.sam = M; g.sak = 1; g.sa1 = M * M; g.sa2 = 0;
+    g.sbk = n; g.sbn = 1; g.sb1 = M * n; g.sb2 = 0;
+    g.ldc = n; g.sc1 = M * n; g.sc2 = 0; g.nb2 = 1;
+    g.tiles_m = cdiv64(M, BM_); g.tiles_n = cdiv64(n, BN_);
+    g.ksplit = 1; g.kper = cdiv64(M, 32) * 32; g.slab = 0;
+    g.flags = NSGP_GEMM_A_LOWER | NSGP_GEMM_NO_SPLITK;
+    g.nbk = (int)batch; g.xcd_chunk = 0; g.xcd_group = 0; g.part_rows = (int)part_rows;
+    g.modeA = 0; g.modeB = 1;
+    g.vecA = (M % 4 == 0) && ((uintptr_t)W % 32 == 0);
+    g.vecB = (n % 4 == 0) && ((uintptr_t)X % 16 == 0);
+    if (g.tiles_m * g.tiles_n > 2147483647LL || batch > 65535) return -24;
+    Epi ep{};
+    ep.kind = 1; ep.rv = rowvec; ep.p0 = part_dot; ep.p1 = part_sq; ep.modeA = 0; ep.modeB = 1;
+    const bool whole = g.vecA && g.vecB && M % BM_ == 0 && n % BN_ == 0 && M % BK_ == 0;
+    constexpr size_t lds = 2 * BK_ * ((BM_ + Mfma<double>::PAD) + (BN_ + Mfma<double>::PAD)) * sizeof(double);
+    dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)batch, 1);
+    hipStream_t st = (hipStream_t)stream;
+    // the kernel takes its B / C pointers as double* and reinterprets them (MIX = 1)
+    const double* Bp = reinterpret_cast<const double*>(X);
+    double* Cp = reinterpret_cast<double*>(Y);
+    if (whole)
+        hipLaunchKernelGGL((gemm_kernel<double, BM_, BN_, BK_, 0, 1, 1, 0, 0, 0, 1>), grid, dim3(256), lds, st, g, 1.0, W, Bp,
+                           0.0, Cp, (double*)nullptr, ep);
+    else
+        hipLaunchKernelGGL((gemm_kernel<double, BM_, BN_, BK_, 0, 1, 1, 0, 0, 1, 1>), grid, dim3(256), lds, st, g, 1.0, W, Bp,
+                           0.0, Cp, (double*)nullptr, ep);
+    return nsgp_launch_status();
+}
+}  // namespace
+
 extern "C" {
+
+size_t nsgp_svgp_f64acc_tiles(int64_t M) { return M > 0 ? (size_t)cdiv64(M, 128) : 0; }
+int nsgp_svgp_tri_gemm_colstats_f64acc(const double* W, const float* X, const float* rowvec, int64_t batch, int64_t M,
+                                       int64_t n, float* Y, float* part_dot, float* part_sq, int64_t part_rows,
+                                       void* stream) {
+    return tri_gemm_colstats_f64acc_impl(W, X, rowvec, batch, M, n, Y, part_dot, part_sq, part_rows, stream);
+}
 
 size_t nsgp_gemm_workspace(int64_t M, int64_t N, int64_t K, int64_t nb1, int64_t nb2, int elem_size, int flags) {
     if (M <= 0 || N <= 0 || K <= 0 || nb1 < 1 || nb2 < 1) return 0;

@@ -196,10 +196,12 @@ class DeepGP(GP):
                 for s in strategies:
                     s._maybe_init()
                 groups = [s.whiten_group() for s in strategies]
-                Ws, _info, passed = whiten(groups, settings.variational_cholesky_jitter.value(args[0].dtype),
-                                           settings.chol_bwd_f64.on(), passthrough=True, out_dtype=args[0].dtype)
-                for s, W, zlo in zip(strategies, Ws, passed):
+                Ws, _info, passed, W64s = whiten(groups, settings.variational_cholesky_jitter.value(args[0].dtype),
+                                                 settings.chol_bwd_f64.on(), passthrough=True, out_dtype=args[0].dtype,
+                                                 with_f64=True)
+                for s, W, zlo, Wd in zip(strategies, Ws, passed, W64s):
                     s._W64_shared = W
+                    s._W64f_shared = Wd                      # float64 companion (forward projection accumulates in it)
                     s._kernel_params_shared = zlo            # (Z, ls, os) routed through the whitening node
                 shared = True
             try:
@@ -208,6 +210,7 @@ class DeepGP(GP):
                 if shared:
                     for s in strategies:
                         s._W64_shared = None
+                        s._W64f_shared = None
                         s._kernel_params_shared = None
 
 

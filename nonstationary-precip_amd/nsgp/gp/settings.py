@@ -115,6 +115,15 @@ class chol_bwd_f64(_feature_flag):
     _state = True
 
 
+class whiten_matmul_f64(_feature_flag):
+    """On (default): the whitened projection A = L^-1 Kzx of a float32 SVGP layer is accumulated in float64 (float64 MFMA
+    on the float32 Kzx, rounded once) -- what the reference computes (a float64 triangular solve cast back).
+    Off: one exact-float32 MFMA GEMM W Kzx, 2x the matrix-core rate on that product; its float32 accumulation of terms
+    |W||Kzx| >> |A| costs ~2e-4 relative on the posterior mean at kappa(Kzz) ~ 1e6 (tools/probes/whiten_precision.py),
+    above the 1e-4 parity bound.  Float64 models are unaffected."""
+    _state = True
+
+
 class check_mvn_cholesky(_feature_flag):
     """On (default): MultivariateNormal.log_prob reads the Cholesky `info` of its dense covariance (one host sync) and
     follows psd_safe_cholesky -- jitter retries with a NumericalWarning, then NotPSDError -- instead of returning a NaN

@@ -113,7 +113,7 @@ class VariationalStrategy(_VariationalStrategy):
         fused, mean_w, mean_c = self._affine_prior_mean(b, x_flat.shape[-1])
         mean, var, _info = svgp_marginal(x_flat, Z, ls.contiguous(), os_.contiguous(), m, Lq, jitter=jitter,
                                          chol_bwd_f64=settings.chol_bwd_f64.on(), W64=W64, mean_w=mean_w,
-                                         mean_c=mean_c)
+                                         mean_c=mean_c, W64f=getattr(self, '_W64f_shared', None) if W64 is not None else None)
         if fused:
             return mean, var
         xin = x_flat if b == 1 and self.inducing_points.dim() == 2 else x_flat.unsqueeze(0).expand(b, *x_flat.shape)
@@ -143,11 +143,16 @@ class VariationalStrategy(_VariationalStrategy):
             jitter = settings.variational_cholesky_jitter.value(x.dtype)
             Kzz = ops.rbf_build(Z.double(), Z.double(), ls.double(), os_.double(), diag_add=jitter)
             L, _ = ops.potrf(Kzz, overwrite=True)
-            W = ops.cast(ops.trtri(L), x.dtype)[0]
+            W64 = ops.trtri(L)[0]
             S, n, D = x.shape
             lsS, osS = ls.expand(S, D).contiguous(), os_.expand(S).contiguous()
             Kzx = ops.rbf_build(Z[0], x, lsS, osS)                         # (S,M,n)
-            A = ops.gemm(W, Kzx, flags=ops.GEMM_A_LOWER)
+            if x.dtype == torch.float32 and settings.whiten_matmul_f64.on():
+                # A = L^-1 Kzx accumulated in float64 like the reference's solve (settings.whiten_matmul_f64); predict
+                # is not a hot path: a plain float64 GEMM on a float64 copy of Kzx
+                A = ops.cast(ops.gemm(W64, ops.cast(Kzx, torch.float64), flags=ops.GEMM_A_LOWER), torch.float32)
+            else:
+                A = ops.gemm(ops.cast(W64, x.dtype), Kzx, flags=ops.GEMM_A_LOWER)
             C = ops.gemm(Lq[0], A, ta=True, flags=ops.GEMM_A_UPPER)
             Kxx = ops.rbf_build(x, x, lsS, osS, diag_add=VAR_JITTER)
             ops.gemm(C, C, ta=True, beta=1.0, out=Kxx)

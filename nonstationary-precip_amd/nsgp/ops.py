@@ -476,11 +476,13 @@ def _affine_args(affine, batch, n, ref):
     return x, sxb, D, w, swb, c, scb
 
 
-def svgp_project(W, Kzx, Lq, m, base, base_add=0.0, affine=None):
+def svgp_project(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None):
     """Fused K6 forward: A = W Kzx, C = Lq^T A (triangular MFMA GEMMs) with the column statistics reduced in
     the GEMM epilogues.  W, Lq:(b,M,M) lower; Kzx:(b,M,n); m:(b,M); base:(b,).
     Returns A, C, mean = A^T m (+ the affine prior mean x w + c, `affine` = (x, w, c)), var = base + base_add +
-    colsum(C^2 - A^2)."""
+    colsum(C^2 - A^2).
+    W64f: the float64 W of a float32 layer -- A is then accumulated in float64 on the float32 Kzx and rounded once
+    (nsgp_svgp_tri_gemm_colstats_f64acc: the reference's float64 solve); W itself (float32) is only used by the backward."""
     ref = _chk(W, Kzx, Lq, m, base)
     W, Kzx, Lq, m, base = _c(W), _c(Kzx), _c(Lq), _c(m), _c(base.reshape(-1))
     batch, M, n = Kzx.shape
@@ -489,15 +491,28 @@ def svgp_project(W, Kzx, Lq, m, base, base_add=0.0, affine=None):
     lib = _lib.load()
     T = int(lib.nsgp_svgp_colstats_tiles(M, n, batch, ref.element_size()))
     A, C = torch.empty_like(Kzx), torch.empty_like(Kzx)
-    part = torch.empty((3, batch, max(T, 1), n), dtype=ref.dtype, device=ref.device)
-    mean = torch.empty((batch, n), dtype=ref.dtype, device=ref.device)
-    var = torch.empty_like(mean)
     sfx, st = _sfx(ref), _stream()
     flops = 1.0 * M * M * n * batch                      # 2 M M n / 2 (triangular operand)
-    _timed(lambda: _lib.call(f'nsgp_svgp_tri_gemm_colstats_{sfx}', _p(W), 0, _p(Kzx), _p(m), batch, M, n, _p(A),
-                             _p(part[0]), _p(part[1]), st), flops, ref.dtype)
+    if W64f is not None:
+        if ref.dtype != torch.float32 or W64f.dtype != torch.float64 or W64f.shape != (batch, M, M) \
+                or W64f.device != ref.device:
+            raise BackendError('svgp_project: W64f must be the float64 (b,M,M) W of a float32 layer')
+        W64f = _c(W64f)
+        T64 = int(lib.nsgp_svgp_f64acc_tiles(M))            # 128-row tiles: never more than the float32 plan's T
+        if T64 > T:
+            raise BackendError('svgp_project: tile-row mismatch between the float64 and float32 projection plans')
+        # tile rows the float64 kernel does not fill (small M only: 64-row float32 tiles vs its 128-row tiles) stay zero
+        part = (torch.zeros if T64 < T else torch.empty)((3, batch, max(T, 1), n), dtype=ref.dtype, device=ref.device)
+        _timed(lambda: _lib.call('nsgp_svgp_tri_gemm_colstats_f64acc', _p(W64f), _p(Kzx), _p(m), batch, M, n, _p(A),
+                                 _p(part[0]), _p(part[1]), T, st), flops, torch.float64)
+    else:
+        part = torch.empty((3, batch, max(T, 1), n), dtype=ref.dtype, device=ref.device)
+        _timed(lambda: _lib.call(f'nsgp_svgp_tri_gemm_colstats_{sfx}', _p(W), 0, _p(Kzx), _p(m), batch, M, n, _p(A),
+                                 _p(part[0]), _p(part[1]), st), flops, ref.dtype)
     _timed(lambda: _lib.call(f'nsgp_svgp_tri_gemm_colstats_{sfx}', _p(Lq), 1, _p(A), None, batch, M, n, _p(C),
                              None, _p(part[2]), st), flops, ref.dtype)
+    mean = torch.empty((batch, n), dtype=ref.dtype, device=ref.device)
+    var = torch.empty_like(mean)
     if affine is None:
         x = w = c = None
         sxb = D = swb = scb = 0

@@ -65,17 +65,20 @@ class WhitenFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)         # no zero-fill launches for outputs nobody differentiated
         # the layers consume W in their own dtype: ONE cast of the batched result here instead of one per layer
         Wout = W64 if out_dtype in (None, torch.float64) else ops.cast(W64, out_dtype)
-        outs, off = [], 0
+        outs, outs64, off = [], [], 0
         for b in ctx.sizes:                      # one output per group (views of the batched result)
             outs.append(Wout[off:off + b])
+            outs64.append(W64[off:off + b].detach() if Wout is not W64 else Wout[off:off + b].detach())
             off += b
-        return (*outs, info, *[t.view_as(t) for t in flat])
+        # the float64 W rides along (non-differentiable): a float32 layer accumulates A = W Kzx in float64 with it
+        ctx.mark_non_differentiable(*outs64)
+        return (*outs, info, *[t.view_as(t) for t in flat], *outs64)
 
     @staticmethod
     def backward(ctx, *gouts):
         W64, *flat = ctx.saved_tensors
         ng = len(ctx.sizes)
-        gpass = gouts[ng + 1:]                               # gradients that came in through the pass-throughs
+        gpass = gouts[ng + 1:ng + 1 + 3 * ng]                # gradients that came in through the pass-throughs
         if ng == 1 and gouts[0] is not None and gouts[0].dtype == W64.dtype:
             Wbar = gouts[0]
         else:                                    # float64 batched Wbar: cast + placement in one multi-tensor copy
@@ -122,14 +125,16 @@ class WhitenFn(torch.autograd.Function):
         return (None, None, None, *outs)
 
 
-def whiten(groups, jitter=1e-4, chol_bwd_f64=True, passthrough=False, out_dtype=None):
+def whiten(groups, jitter=1e-4, chol_bwd_f64=True, passthrough=False, out_dtype=None, with_f64=False):
     """groups: list of (Z:(b,M,D), ls:(b,D), os:(b,)).  Returns (list of W:(b,M,M) per group -- float64 unless
     `out_dtype` asks for the layers' dtype --, info); with
-    passthrough=True also the list of (Z, ls, os) pass-through triples a layer should build its Kzx from (WhitenFn)."""
+    passthrough=True also the list of (Z, ls, os) pass-through triples a layer should build its Kzx from (WhitenFn);
+    with_f64=True appends the list of float64 W per group (non-differentiable companions of the float32 W: the forward
+    projection of a float32 layer accumulates in float64 with them, settings.whiten_matmul_f64)."""
     flat = [t for g in groups for t in g]
     res = WhitenFn.apply(float(jitter), bool(chol_bwd_f64), out_dtype, *flat)
     ng = len(groups)
-    Ws, info, rest = res[:ng], res[ng], res[ng + 1:]
+    Ws, info, rest, W64s = res[:ng], res[ng], res[ng + 1:ng + 1 + 3 * ng], res[ng + 1 + 3 * ng:]
     from .gp import settings
     if settings.check_variational_cholesky.on():
         bad = info.nonzero()
@@ -138,9 +143,12 @@ def whiten(groups, jitter=1e-4, chol_bwd_f64=True, passthrough=False, out_dtype=
             b = int(bad[0, 0])
             raise NotPSDError(f'Kzz + {jitter:g} I of GP {b} (of {info.numel()} in the whitening chain) is not positive '
                               f'definite: leading minor {int(info[b])} failed')
+    out = [list(Ws), info]
     if passthrough:
-        return list(Ws), info, [tuple(rest[3 * i:3 * i + 3]) for i in range(ng)]
-    return list(Ws), info
+        out.append([tuple(rest[3 * i:3 * i + 3]) for i in range(ng)])
+    if with_f64:
+        out.append(list(W64s))
+    return tuple(out)
 
 
 class SVGPLayerFn(torch.autograd.Function):
@@ -157,11 +165,16 @@ class SVGPLayerFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, Z, ls, os_, m, Lq, W64, mean_w, mean_c):
+    def forward(ctx, x, Z, ls, os_, m, Lq, W64, mean_w, mean_c, W64f=None):
         W = W64 if W64.dtype == x.dtype else ops.cast(W64, x.dtype)
+        if W64f is None and W64.dtype == torch.float64 and x.dtype == torch.float32:
+            W64f = W64
+        from .gp import settings
+        if x.dtype != torch.float32 or not settings.whiten_matmul_f64.on():
+            W64f = None
         Kzx = ops.rbf_build(Z, x, ls, os_)                                       # (b,M,n)
         affine = None if (mean_w is None and mean_c is None) else (x, mean_w, mean_c)
-        A, C, mean, var = ops.svgp_project(W, Kzx, Lq, m, os_, base_add=VAR_JITTER, affine=affine)   # 2 GEMMs
+        A, C, mean, var = ops.svgp_project(W, Kzx, Lq, m, os_, base_add=VAR_JITTER, affine=affine, W64f=W64f)   # 2 GEMMs
         ctx.save_for_backward(x, Z, ls, os_, m, Lq, W, Kzx, A, C, mean_w, mean_c)
         ctx.w_dtype = W64.dtype
         return mean, var
@@ -186,16 +199,16 @@ class SVGPLayerFn(torch.autograd.Function):
         return (gx if need_x else None, gZ, gls.reshape(ls.shape), gos.reshape(os_.shape), mbar, Lqbar,
                 Wbar if Wbar.dtype == ctx.w_dtype else ops.cast(Wbar, ctx.w_dtype),
                 None if mean_w is None else wbar.reshape(mean_w.shape),
-                None if mean_c is None else cbar.reshape(mean_c.shape))
+                None if mean_c is None else cbar.reshape(mean_c.shape), None)
 
 
-def svgp_marginal(x, Z, ls, os_, m, Lq, jitter=1e-4, chol_bwd_f64=True, W64=None, mean_w=None, mean_c=None):
+def svgp_marginal(x, Z, ls, os_, m, Lq, jitter=1e-4, chol_bwd_f64=True, W64=None, mean_w=None, mean_c=None, W64f=None):
     """mean and variance of q(f) at x for b whitened SVGPs; the mean excludes the prior mean function unless its
     affine parameters are passed (mean_w: LinearMean weights (D,) / (b,D), mean_c: constant or bias (1,) / (b,)).
     Returns (mean, var, info); pass W64 (from `whiten`) to share one factorisation chain across layers."""
     info = None
     if W64 is None:
-        (W64,), info, ((Z, ls, os_),) = whiten([(Z, ls, os_)], jitter, chol_bwd_f64, passthrough=True,
-                                               out_dtype=x.dtype)
-    mean, var = SVGPLayerFn.apply(x, Z, ls, os_, m, Lq, W64, mean_w, mean_c)
+        (W64,), info, ((Z, ls, os_),), (W64f,) = whiten([(Z, ls, os_)], jitter, chol_bwd_f64, passthrough=True,
+                                                        out_dtype=x.dtype, with_f64=True)
+    mean, var = SVGPLayerFn.apply(x, Z, ls, os_, m, Lq, W64, mean_w, mean_c, W64f)
     return mean, var, info

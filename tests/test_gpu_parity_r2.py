@@ -80,7 +80,7 @@ def test_matrix_variate_normal_prior_values_match_oracle():
     # (kappa ~ 1e5: a few 1e-3 of its own largest entry off); this path inverts it with the float64 MFMA Cholesky and
     # rounds once.  Held to the float64 inverse at float32 round-off, and to the reference-style float32 inverse at that
     # inverse's own accuracy.
-    rowj64 = row.double() + 1e-5 * torch.eye(n, dtype=F64)
+    rowj64 = (row + 1e-5 * torch.eye(n)).double()       # the jitter is added in float32, as the reference does (:45)
     inv64 = torch.kron(torch.linalg.inv(col.double()), torch.linalg.inv(rowj64))
     scale = float(inv64.abs().max())
     assert float((pr.kron_cov_inv.cpu().double() - inv64).abs().max()) < 1e-5 * scale
