@@ -30,8 +30,10 @@ os_ = torch.ones(b).cuda()
 Cc = torch.randn(b, M, n, generator=g).cuda()
 tri = M * M * n * b
 
+W64 = W.double()
 cases = [
     ('fwd  A=W K, C=Lq^T A (+colstats)', lambda: ops.svgp_project(W, K, Lq, m, os_), 2 * tri),
+    ('fwd  same, A accumulated in f64 ', lambda: ops.svgp_project(W, K, Lq, m, os_, W64f=W64), 2 * tri),
     ('bwd  Abar (epi 2) + Lqbar (ksc)  ', lambda: ops.svgp_project_bwd(Lq, m, A, Cc, gm, gv), 2 * tri),
     ('bwd  Kzxbar = W^T Abar  A_UPPER  ', lambda: ops.gemm(W, A, ta=True, flags=ops.GEMM_A_UPPER), tri),
     ('bwd  Wbar = tril(Abar Kzx^T)     ', lambda: ops.gemm(A, K, tb=True, flags=ops.GEMM_C_LOWER), tri),
