@@ -70,3 +70,46 @@ def sgpr_predict(x_train, y_train, Z, log_ell_z, outputscale, noise, prior, x_ne
         Kss = Kss + torch.diag(float(outputscale) * corr)
     cov = Kss - Lr @ ((torch.eye(M, dtype=x_train.dtype) - torch.inverse(B)) @ Lr.transpose(-1, -2))  # :147-150
     return mean, cov
+
+
+# ---------------------------------------------------------------------------------------------------------
+# gpytorch.kernels.InducingPointKernel over an arbitrary base kernel [recalled, SURVEY 3.5 / A.5]: SGPR low-rank
+# covariance Q = K_xz Kzz^-1 K_zx, Titsias trace term in training, clamped diagonal correction in eval mode.
+# Used with the sparse Paciorek-Schervish kernel (BASELINE configs[2]: models/sparse_multivariate_gibbs_kernel.py
+# defines K only for x1 == x2 and for pairs where one side is the M inducing locations, which is exactly what an
+# inducing-point GP needs).
+# ---------------------------------------------------------------------------------------------------------
+def ipk_root(Kzz, Kxz):
+    """root = K_xz R, R = U^-1 with Kzz = U^T U (triangular_solve(I, chol_upper(Kzz)))."""
+    U = torch.linalg.cholesky(Kzz).transpose(-1, -2)
+    R = torch.linalg.solve_triangular(U, torch.eye(U.shape[-1], dtype=U.dtype), upper=True)
+    return Kxz @ R
+
+
+def ipk_mll(Kzz, Kxz, kdiag, y, noise, mean=None):
+    """ExactMarginalLogLikelihood of an ExactGP whose covar_module is an InducingPointKernel (training mode):
+    [log N(y | mu, Q + noise I) - 1/2 sum_i (k_ii - q_ii) / noise] / N."""
+    n = y.shape[-1]
+    root = ipk_root(Kzz, Kxz)
+    Q = root @ root.transpose(-1, -2)
+    mu = torch.zeros_like(y) if mean is None else mean
+    lp = mvn_log_prob(y, mu, Q + noise * torch.eye(n, dtype=y.dtype))
+    lp = lp - 0.5 * ((kdiag - torch.diagonal(Q)) / noise).sum()
+    return lp / n
+
+
+def ipk_predict(Kzz, Kxz, kdiag_x, Ksz, kdiag_s, y, noise, with_noise=True):
+    """Eval-mode prediction (sgpr_diagonal_correction on): train covariance Q_xx + diag(clamp(k - q, 0)) + noise I,
+    cross covariance Q_sx, test covariance Q_ss + diag(clamp(k - q, 0)) (+ noise I for likelihood(model(x)))."""
+    n = y.shape[-1]
+    R = ipk_root(Kzz, torch.eye(Kzz.shape[-1], dtype=Kzz.dtype))          # = U^-1
+    rx, rs = Kxz @ R, Ksz @ R
+    Qxx, Qsx, Qss = rx @ rx.T, rs @ rx.T, rs @ rs.T
+    Kt = Qxx + torch.diag((kdiag_x - torch.diagonal(Qxx)).clamp(0, math.inf)) + noise * torch.eye(n, dtype=y.dtype)
+    L = torch.linalg.cholesky(Kt)
+    mean = Qsx @ torch.cholesky_solve(y.unsqueeze(-1), L).squeeze(-1)
+    V = torch.linalg.solve_triangular(L, Qsx.T, upper=False)
+    cov = Qss + torch.diag((kdiag_s - torch.diagonal(Qss)).clamp(0, math.inf)) - V.T @ V
+    if with_noise:
+        cov = cov + noise * torch.eye(Ksz.shape[-2], dtype=y.dtype)
+    return mean, cov

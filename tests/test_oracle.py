@@ -475,3 +475,27 @@ def test_sparse_spatiotemporal_nonstationary_restatement():
     xs = torch.randn(5, 3, generator=g, dtype=F64)
     m, c = st.st_ns_predict(x, y, z.detach(), lez.detach(), p, noise, prior, xs)
     assert m.shape == (5,) and c.shape == (5, 5) and bool(torch.isfinite(m).all()) and bool(torch.isfinite(c).all())
+
+
+def test_generic_inducing_point_kernel_restatement_reduces_to_the_exact_gp_at_z_equal_x():
+    """oracle.sparse.ipk_mll / ipk_predict (gpytorch InducingPointKernel over any base kernel): with Z = X the low-rank
+    covariance is exact, so the objective is the exact-GP log marginal likelihood / N (trace term 0) and the
+    prediction is the exact-GP posterior."""
+    g = _g(31)
+    n, ns = 25, 7
+    x = torch.randn(n, 2, generator=g, dtype=F64)
+    xs = torch.randn(ns, 2, generator=g, dtype=F64)
+    y = torch.randn(n, generator=g, dtype=F64)
+    ls = torch.tensor([[0.8, 1.1]], dtype=F64)
+    Kxx = K.rbf_ard(x, x, ls, 0.9) + 1e-9 * torch.eye(n, dtype=F64)
+    Ksx, Kss = K.rbf_ard(xs, x, ls, 0.9), K.rbf_ard(xs, xs, ls, 0.9)
+    noise = 0.2
+    val = sparse.ipk_mll(Kxx, Kxx, torch.diagonal(Kxx), y, noise)
+    ref = exact.mvn_log_prob(y, torch.zeros_like(y), Kxx + noise * torch.eye(n, dtype=F64)) / n
+    assert abs(float(val) - float(ref)) < 1e-6 * abs(float(ref))
+    m, c = sparse.ipk_predict(Kxx, Kxx, torch.diagonal(Kxx), Ksx, torch.diagonal(Kss), y, noise, with_noise=False)
+    Kn = Kxx + noise * torch.eye(n, dtype=F64)
+    m_ref = Ksx @ torch.linalg.solve(Kn, y)
+    v_ref = torch.diagonal(Kss - Ksx @ torch.linalg.solve(Kn, Ksx.T))
+    assert torch.allclose(m, m_ref, rtol=1e-6, atol=1e-8)
+    assert torch.allclose(torch.diagonal(c), v_ref, rtol=1e-5, atol=1e-7)
