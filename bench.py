@@ -7,12 +7,13 @@
 
 Workload (BASELINE B4): DeepGP(num_layers=1) = hidden 3->2 + last 2->1, M=1024 inducing,
 S=10 likelihood samples, minibatch B=4096 of a synthetic N=100,000 spatio-temporal grid
-(100 months x 1,000 cells, time-major, z-scored), float32 with float64 Kzz Cholesky, Adam lr 0.01.
+(100 months x 1,000 cells, time-major, z-scored), float32 with float64 Kzz Cholesky and a float64-accumulated
+whitened projection (settings.whiten_matmul_f64: the reference's float64 solve), Adam lr 0.01.
 One step = forward + ELBO + backward + (gradient all-reduce) + Adam update on one 4096-row minibatch that
-is already resident in HBM.  With N>1 (data parallel, nsgp/dist.py) every rank takes its own 4096 rows of a
-global minibatch of 4096 N rows (weak scaling, the default: value = N x iterations/s) or, with
---scaling strong, 4096/N rows of ONE 4096-row minibatch (value = iterations/s); either way the ranks'
-objectives sum to the single-process ELBO of the global minibatch and the flat gradient bucket is summed
+is already resident in HBM.  With N > 1 (data parallel, nsgp/dist.py) the default is SURVEY 8e's split: ONE
+4096-row minibatch is shared by the N ranks (4096/N rows each; `"scaling": "strong"`, value = iterations/s);
+`--scaling weak` gives every rank its own 4096 rows (global batch 4096 N, value = N x iterations/s).  Either way the
+ranks' objectives sum to the single-process ELBO of the global minibatch and the flat gradient bucket is summed
 with one RCCL all-reduce.
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field definitions).
@@ -33,6 +34,7 @@ import torch.distributed as dist  # noqa: E402
 
 M_INDUCING, S_SAMPLES, BATCH, N_DATA, SEED = 1024, 10, 4096, 100_000, 173
 MFMA_F32_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+MFMA_F64_PEAK_TFLOPS = 78.6           # v_mfma_f64_16x16x4_f64: half the f32 matrix rate
 HBM_PEAK_GBS = 8000.0
 
 
@@ -85,17 +87,31 @@ def build(device, dp_world):
     return model, mll, opt
 
 
+def gemm_source_sha():
+    """sha256 of the GEMM kernel source: PMC traffic figures are only valid for the code they were measured on."""
+    import hashlib
+    path = os.path.join(ROOT, 'nonstationary-precip_amd', 'csrc', 'gemm.hip')
+    try:
+        return hashlib.sha256(open(path, 'rb').read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def gemm_traffic(world, share):
     """`traffic`: average L2<->fabric bytes per f32 GEMM launch of a step, from the committed rocprofv3 PMC passes of
-    this same single-GPU workload (tools/gemm_traffic.py -> profiles/r01/gemm_traffic.json).  PMC counters cannot be
-    read from inside the process, so this is the recorded measurement, not a live one; null when it does not apply."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01', 'gemm_traffic.json')
+    this same single-GPU workload (tools/gemm_traffic.py -> profiles/r02/gemm_traffic.json).  PMC counters cannot be
+    read from inside the process, so this is the recorded measurement, not a live one; it is reported only while the
+    GEMM source still hashes to what the passes were taken on (null otherwise, and for N > 1)."""
+    path = os.path.join(ROOT, 'profiles', 'r02', 'gemm_traffic.json')
     if world != 1 or share != 1 or not os.path.exists(path):
         return {'traffic': None}
     try:
         d = json.load(open(path))
+        if d.get('gemm_source_sha') != gemm_source_sha():
+            return {'traffic': None, 'traffic_note': 'profiles/r02/gemm_traffic.json is stale (gemm.hip changed since the PMC passes)'}
         return {'traffic': round(float(d['bytes_per_launch'])), 'traffic_unit': 'bytes per launch (FETCH_SIZE x2 + '
-                'WRITE_SIZE, incl. Infinity-Cache hits)', 'traffic_source': 'profiles/r01/gemm_traffic.json'}
+                'WRITE_SIZE, incl. Infinity-Cache hits)', 'traffic_source': 'profiles/r02/gemm_traffic.json',
+                'algorithmic_bytes_per_launch': d.get('algorithmic_bytes_per_launch')}
     except (OSError, ValueError, KeyError):
         return {'traffic': None}
 
@@ -112,9 +128,11 @@ def host_cores():
     return max(1, n)
 
 
-def cpu_baseline(x, y, idx, seconds_budget=25.0):
-    """The oracle's gpytorch-mirroring op sequence (float32, float64 Cholesky/solve, per-sample Kzz
-    recomputation) for the same model/minibatch on the host cores: forward + backward + Adam."""
+def cpu_baseline(x, y, idx, seconds_budget=14.0, mirror=True):
+    """The oracle's op sequence for the same model/minibatch on the host cores: forward + backward + Adam.
+    mirror=True: gpytorch's own sequence (float32, float64 Cholesky/solve, per-sample Kzz recomputation in the last layer
+    [recalled]); mirror=False: the same arithmetic with Kzz / Cholesky computed once per layer (the redundancy-free
+    restatement, a stronger baseline)."""
     from oracle import svgp
     g = torch.Generator().manual_seed(SEED)
     M, D = M_INDUCING, 3
@@ -135,13 +153,13 @@ def cpu_baseline(x, y, idx, seconds_budget=25.0):
     t_all = time.perf_counter()
     step = 0
     while True:
-        rows = idx[step % len(idx)]
+        rows = idx[step % len(idx)][:BATCH]
         xb, yb = x[rows], y[rows]
         eps = [torch.randn(S_SAMPLES, BATCH, 2, generator=g)]
         t0 = time.perf_counter()
         hidden = dict(Z=hZ, lengthscale=sp(h_rl), outputscale=sp(h_ro), m=hm, Lq=hL, mean=('linear', hw, hb))
         last = dict(Z=lZ, lengthscale=sp(l_rl), outputscale=sp(l_ro), m=lm, Lq=lL, mean=('constant', lc))
-        loss = -svgp.dsvi_elbo(xb, yb, hidden, last, 1, eps, S_SAMPLES, sp(rn) + 1e-4, N_DATA, mirror=True)
+        loss = -svgp.dsvi_elbo(xb, yb, hidden, last, 1, eps, S_SAMPLES, sp(rn) + 1e-4, N_DATA, mirror=mirror)
         grads = torch.autograd.grad(loss, params)
         with torch.no_grad():
             new = svgp.adam_step([p.detach() for p in params], list(grads), state)
@@ -149,41 +167,147 @@ def cpu_baseline(x, y, idx, seconds_budget=25.0):
                 p.copy_(q)
         times.append(time.perf_counter() - t0)
         step += 1
-        if step >= 2 and (time.perf_counter() - t_all > seconds_budget or step >= 6):
+        if step >= 2 and (time.perf_counter() - t_all > seconds_budget or step >= 5):
             break
     use = times[1:] if len(times) > 1 else times
     return len(use) / sum(use), len(times)
 
 
-def gibbs_chol_ms(device):
-    """Second half of the BASELINE metric: Gibbs K build + Cholesky at N=4096, D=2 (B2), fp64 and fp32."""
-    from nsgp import ops
-    out = {}
-    n = 4096
-    g = torch.Generator().manual_seed(SEED)
-    for dt, tag in ((torch.float64, 'f64'), (torch.float32, 'f32')):
-        x = torch.randn(n, 2, generator=g).to(device=device, dtype=dt)
-        e = torch.exp(0.3 * torch.randn(2, n, generator=g) + math.log(0.3)).to(device=device, dtype=dt)
-        os_ = torch.tensor([0.644], dtype=dt, device=device)
-        nz = torch.tensor([0.011], dtype=dt, device=device)
+def _timeit(fn, reps=10):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
 
-        def timeit(fn, reps=10):
-            fn()
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                fn()
-            e1.record()
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1) / reps
-        out[f'gibbs_build_ms_{tag}'] = round(timeit(lambda: ops.gibbs_build(x, x, e, e, os_, nz)), 4)
-        K = ops.gibbs_build(x, x, e, e, os_, nz)
-        out[f'potrf_ms_{tag}'] = round(timeit(lambda: ops.potrf(K), reps=5), 4)
-        bytes_ = K.element_size() * (n * n + 2 * 2 * (n + n))
-        out[f'gibbs_build_GBs_{tag}'] = round(bytes_ / (out[f'gibbs_build_ms_{tag}'] * 1e-3) / 1e9, 1)
-        out[f'potrf_TFLOPs_{tag}'] = round(n ** 3 / 3 / (out[f'potrf_ms_{tag}'] * 1e-3) / 1e12, 3)
-    out['gibbs_map_step_ms_f64'] = gibbs_map_step_ms(device, n)
+
+def _b2_inputs(n, device, dt):
+    """BASELINE B2 inputs: N = 394 is the real data/uib_spatial.csv (z-scored lon/lat); otherwise a regular lattice,
+    z-scored; ell = exp(0.3 N(0,1) + log 0.3) in the reference's (D, N) layout."""
+    g = torch.Generator().manual_seed(SEED)
+    if n == 394:
+        import pandas as pd
+        d = pd.read_csv(os.path.join(ROOT, 'tests', 'golden', 'data', 'uib_spatial.csv'))
+        x = torch.tensor(d[['lon', 'lat']].values, dtype=torch.float64)
+    else:
+        side = int(round(n ** 0.5))
+        gx, gy = torch.meshgrid(torch.arange(side, dtype=torch.float64), torch.arange(n // side, dtype=torch.float64),
+                                indexing='ij')
+        x = torch.stack([gx.reshape(-1), gy.reshape(-1)], -1)
+    x = (x - x.mean(0)) / x.std(0)
+    ell = torch.exp(0.3 * torch.randn(2, x.shape[0], generator=g, dtype=torch.float64) + math.log(0.3))
+    return x.to(device=device, dtype=dt), ell.to(device=device, dtype=dt)
+
+
+def build_chol_table(device, with_cpu=True):
+    """Second half of the BASELINE metric (B2): Gibbs K build + potrf(sigma_f^2 K + sigma^2 I) at
+    N in {394 (real CSV), 1024, 4096, 16384}, D = 2, float32 and float64, with GB/s (algorithmic bytes of the build) and
+    TFLOP/s (N^3/3) -- and, beside each, the CPU oracle timed on the host cores: the reference's own op sequence for the
+    build (oracle.kernels.gibbs, 8 full-size temporaries) and torch.linalg.cholesky.  At N = 16384 the CPU build is timed
+    on a 1024-row slab and scaled (its temporaries would need 6 x 4.3 GB); the CPU Cholesky is the full matrix."""
+    from nsgp import ops
+    from oracle import kernels as OK
+    rows = []
+    for n in (394, 1024, 4096, 16384):
+        for dt, tag in ((torch.float32, 'f32'), (torch.float64, 'f64')):
+            x, e = _b2_inputs(n, device, dt)
+            nn = x.shape[0]
+            os_ = torch.tensor([0.644], dtype=dt, device=device)
+            nz = torch.tensor([0.011], dtype=dt, device=device)
+            t_build = _timeit(lambda: ops.gibbs_build(x, x, e, e, os_, nz), reps=20 if nn <= 4096 else 5)
+            K = ops.gibbs_build(x, x, e, e, os_, nz)
+            t_chol = _timeit(lambda: ops.potrf(K), reps=10 if nn <= 4096 else 2)
+            _, info = ops.potrf(K)
+            bytes_ = K.element_size() * (nn * nn + 2 * 2 * (nn + nn))
+            row = {'N': nn, 'dtype': tag, 'build_ms': round(t_build, 4), 'build_GBs': round(bytes_ / t_build / 1e6, 1),
+                   'build_frac_hbm': round(bytes_ / t_build / 1e6 / HBM_PEAK_GBS, 3),
+                   'potrf_ms': round(t_chol, 4), 'potrf_TFLOPs': round(nn ** 3 / 3 / t_chol / 1e9, 3),
+                   'potrf_info': int(info.max().item())}
+            del K
+            if with_cpu:
+                xc, ec = x.cpu(), e.cpu()
+                slab = min(nn, 1024 if nn > 4096 else nn)
+                t0 = time.perf_counter()
+                reps = 3 if nn <= 1024 else 1
+                for _ in range(reps):
+                    Kc = 0.644 * OK.gibbs(xc[:slab], xc, ec[:, :slab], ec)
+                t_cb = (time.perf_counter() - t0) / reps * (nn / slab)
+                del Kc
+                Kfull = (0.644 * OK.gibbs(xc, xc, ec, ec) if nn <= 4096 else None)
+                if Kfull is None:          # N = 16384: a well-conditioned SPD stand-in of the same size for the CPU Cholesky
+                    gq = torch.Generator().manual_seed(1)
+                    Q = torch.randn(nn, 64, generator=gq, dtype=dt)
+                    Kfull = Q @ Q.T
+                Kfull.diagonal().add_(0.011 if nn <= 4096 else 1.0)
+                t0 = time.perf_counter()
+                torch.linalg.cholesky(Kfull)
+                t_cc = time.perf_counter() - t0
+                del Kfull
+                row.update(cpu_build_ms=round(t_cb * 1e3, 2), cpu_potrf_ms=round(t_cc * 1e3, 2),
+                           cpu_build_sample=('full' if slab == nn else f'{slab}-row slab, scaled'))
+            rows.append(row)
+    return rows
+
+
+def b3_sparse_multivariate_step_ms(device):
+    """BASELINE B3: one training step (objective, backward, Adam) of the inducing-point GP over
+    SparseMultivariateGibbsKernel, M = 512, on the 5,676 rows of uib_spatio_temporal.csv, float32
+    (tests/test_gpu_cfg2.py holds the parity of this model)."""
+    import pandas as pd
+    import nsgp.gp as gpytorch
+    from sklearn.cluster import KMeans
+    from models.sparse_multivariate_gibbs_kernel import SparseMultivariateGibbsKernel
+    d = pd.read_csv(os.path.join(ROOT, 'tests', 'golden', 'data', 'uib_spatio_temporal.csv'))
+    xy = torch.tensor(d[['lon', 'lat']].values, dtype=torch.float32)
+    y = torch.tensor(d['tp'].values, dtype=torch.float32)
+    sx, mx = torch.std_mean(xy, dim=0)
+    sy, my = torch.std_mean(y)
+    x, y = ((xy - mx) / sx).to(device), ((y - my) / sy).to(device)
+    Z = torch.tensor(KMeans(512, n_init=1, random_state=SEED).fit(x.cpu().numpy()).cluster_centers_, dtype=torch.float32)
+    Z = (Z + 0.05 * torch.randn(Z.shape, generator=torch.Generator().manual_seed(0))).to(device)
+
+    class SparsePSGP(gpytorch.models.ExactGP):
+        def __init__(self, train_x, train_y, likelihood):
+            super().__init__(train_x, train_y, likelihood)
+            self.mean_module = gpytorch.means.ZeroMean()
+            base = gpytorch.kernels.ScaleKernel(SparseMultivariateGibbsKernel(Z, 2, Z.clone()))
+            self.covar_module = gpytorch.kernels.InducingPointKernel(base, inducing_points=Z.clone(), likelihood=likelihood)
+            self.covar_module.inducing_points.requires_grad = False
+
+        def forward(self, xx):
+            return gpytorch.distributions.MultivariateNormal(self.mean_module(xx), self.covar_module(xx))
+    torch.manual_seed(3)
+    lik = gpytorch.likelihoods.GaussianLikelihood()
+    model = SparsePSGP(x, y, lik).to(device)
+    model.train(); lik.train()
+    mll = gpytorch.mlls.ExactMarginalLogLikelihood(lik, model)
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=0.01)
+
+    def step():
+        opt.zero_grad()
+        loss = -mll(model(model.train_inputs[0]), model.train_targets)
+        loss.backward()
+        opt.step()
+    return round(_timeit(step, reps=3), 3)
+
+
+def gibbs_chol_ms(device, with_cpu=True):
+    """BASELINE B2 table + the N = 4096 figures as flat fields (the metric's second half) + the float64 MAP step."""
+    table = build_chol_table(device, with_cpu=with_cpu)
+    out = {'build_chol': table}
+    for row in table:
+        if row['N'] == 4096:
+            tag = row['dtype']
+            out[f'gibbs_build_ms_{tag}'] = row['build_ms']
+            out[f'gibbs_build_GBs_{tag}'] = row['build_GBs']
+            out[f'potrf_ms_{tag}'] = row['potrf_ms']
+            out[f'potrf_TFLOPs_{tag}'] = row['potrf_TFLOPs']
+    out['gibbs_map_step_ms_f64'] = gibbs_map_step_ms(device, 4096)
+    out['b3_sparse_multivariate_step_ms_f32'] = b3_sparse_multivariate_step_ms(device)
     return out
 
 
@@ -243,10 +367,10 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly (no hipGraph replay)')
     ap.add_argument('--no-build-chol', action='store_true',
                     help='skip the Gibbs-build + Cholesky fields (PMC passes of the DSVI step only)')
-    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
-                    help='weak (default): every GPU takes its own 4096-row minibatch per iteration (global batch '
-                         '4096 x N), value = N x iterations/s; strong: ONE 4096-row minibatch is split over the N GPUs, '
-                         'value = iterations/s.  Identical at N=1.')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='strong',
+                    help='strong (default, SURVEY 8e): ONE 4096-row minibatch is split over the N GPUs (4096/N rows each), '
+                         'value = iterations/s; weak: every GPU takes its own 4096-row minibatch per iteration (global batch '
+                         '4096 x N), value = N x iterations/s.  Identical at N=1.')
     ap.add_argument('--split-graph', action='store_true',
                     help='analysis only (N=1): replay the step as the TWO graphs an N>1 run uses (forward+backward, then Adam) '
                          'with the eager gradient all-reduce call between them (a no-op at N=1), to price the split')
@@ -280,7 +404,7 @@ def main():
     x_all, y_all = synthetic_grid()
     gperm = torch.Generator().manual_seed(SEED)
     perm = torch.randperm(N_DATA, generator=gperm)
-    weak = args.scaling == 'weak'
+    weak = args.scaling == 'weak' and world > 1
     gbatch = BATCH * world if weak else BATCH                     # rows of one global minibatch
     n_batches = N_DATA // gbatch
     idx = [perm[i * gbatch:(i + 1) * gbatch] for i in range(n_batches)]     # shared shuffled index
@@ -390,6 +514,7 @@ def main():
             adam_step()
         gemm_ms, gemm_flops, gemm_launches = timer.summary(torch.float32)
         g64_ms, g64_flops, g64_launches = timer.summary(torch.float64)
+        acc_ms, acc_flops, acc_launches = timer.summary('f64acc')
         ops.set_gemm_timer(None)
 
     result = None
@@ -403,7 +528,7 @@ def main():
             'metric': 'dsvi_elbo_steps_per_sec',
             'value': round((world if weak else 1) * args.steps / elapsed, 3), 'unit': 'steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
-            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32',
+            'higher_is_better': True, 'scaling': ('weak' if weak else 'strong'), 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic',
             'config': {'workload': '2-layer DSVI DeepGP (hidden 3->2 + last 2->1), M=1024, S=10, minibatch 4096 '
                                    + ('per GPU ' if weak else '(global, split over the GPUs) ')
@@ -412,6 +537,7 @@ def main():
                        'global_batch': gbatch, 'N': N_DATA, 'parallelism': f'dp{world}',
                        'kzz_cholesky_dtype': 'f64', 'hipgraph': bool(use_graph)},
             'iterations_per_sec': round(args.steps / elapsed, 3),
+            'rows_per_sec': round(gbatch * args.steps / elapsed, 1),
             **({'analysis_split_graph': 'two graph replays per step, as in an N>1 run'} if args.split_graph else {}),
             **({'analysis': f'one rank\'s share of a {share}-rank job (rows [0, {hi - lo}) of each minibatch), '
                             'no collective; NOT a --gpus result'} if share > 1 else {}),
@@ -424,18 +550,30 @@ def main():
                          'algorithmic_gflop_per_step': round(gemm_flops / nprof / 1e9, 2),
                          'f64_gemm_ms_per_step': round(g64_ms / nprof, 3),
                          'f64_gemm_launches_per_step': g64_launches // nprof},
+            # the whitened projection A = L^-1 Kzx, accumulated in float64 on the float32 Kzx (settings.whiten_matmul_f64):
+            # float64 MFMA, priced against the 78.6 TFLOP/s float64 matrix peak
+            'f64acc_projection': ({'ms_per_step': round(acc_ms / nprof, 3), 'launches_per_step': acc_launches // nprof,
+                                   'algorithmic_gflop_per_step': round(acc_flops / nprof / 1e9, 2),
+                                   'achieved': round(acc_flops / (acc_ms * 1e-3) / 1e12, 2), 'peak': MFMA_F64_PEAK_TFLOPS,
+                                   'unit': 'TFLOP/s', 'frac': round(acc_flops / (acc_ms * 1e-3) / 1e12 / MFMA_F64_PEAK_TFLOPS, 4)}
+                                  if acc_launches else None),
         }
         if world == 1:
             if not args.no_build_chol:
                 result.update(gibbs_chol_ms(device))
             if not args.no_cpu_baseline:
                 torch.set_num_threads(host_cores())
-                v, nsteps = cpu_baseline(x_all, y_all, idx)
+                v, nsteps = cpu_baseline(x_all, y_all, idx, mirror=True)
+                v2, nsteps2 = cpu_baseline(x_all, y_all, idx, mirror=False)
                 result['cpu_baseline'] = {'value': round(v, 4), 'unit': 'steps/s', 'cores': torch.get_num_threads(),
                                           'kind': 'port',
                                           'sample': f'{nsteps} full DSVI steps (first discarded) of the same '
-                                                    'M=1024/S=10/B=4096 workload, oracle in gpytorch-mirror mode'}
+                                                    'M=1024/S=10/B=4096 workload, oracle in gpytorch-mirror mode',
+                                          # the same arithmetic WITHOUT the [recalled] per-sample Kzz / Cholesky recomputation
+                                          'value_no_mirror': round(v2, 4),
+                                          'sample_no_mirror': f'{nsteps2} steps, Kzz + Cholesky once per layer'}
                 result['speedup_vs_cpu'] = round(result['value'] / v, 1)
+                result['speedup_vs_cpu_no_mirror'] = round(result['value'] / v2, 1)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

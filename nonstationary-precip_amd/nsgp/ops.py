@@ -504,7 +504,7 @@ def svgp_project(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None):
         # tile rows the float64 kernel does not fill (small M only: 64-row float32 tiles vs its 128-row tiles) stay zero
         part = (torch.zeros if T64 < T else torch.empty)((3, batch, max(T, 1), n), dtype=ref.dtype, device=ref.device)
         _timed(lambda: _lib.call('nsgp_svgp_tri_gemm_colstats_f64acc', _p(W64f), _p(Kzx), _p(m), batch, M, n, _p(A),
-                                 _p(part[0]), _p(part[1]), T, st), flops, torch.float64)
+                                 _p(part[0]), _p(part[1]), T, st), flops, 'f64acc')
     else:
         part = torch.empty((3, batch, max(T, 1), n), dtype=ref.dtype, device=ref.device)
         _timed(lambda: _lib.call(f'nsgp_svgp_tri_gemm_colstats_{sfx}', _p(W), 0, _p(Kzx), _p(m), batch, M, n, _p(A),

@@ -84,3 +84,47 @@ def test_two_rank_data_parallel_training_equals_single_process(tmp_path):
     assert a['losses'][-1] < a['losses'][0]
     assert float((a['p'] - b['p']).abs().max()) < 2e-3
     assert float((a['p'] - b['p']).abs().mean()) < 2e-5
+
+
+def _bench_line(nproc, extra, port):
+    """Run bench.py the way the driver launches it (torch.distributed.run for N > 1) and return its JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NSGP_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    common = ['--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-build-chol'] + extra
+    if nproc == 1:
+        cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1'] + common
+    else:
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={nproc}',
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(root, 'bench.py'),
+               '--gpus', str(nproc)] + common
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]                     # rank 0 prints ONE line
+    return json.loads(lines[0])
+
+
+def test_bench_two_rank_control_flow_matches_one_rank():
+    """The N > 1 control flow of bench.py itself -- two hipGraph replays (forward + backward, Adam) around the eager
+    gradient all-reduce, barrier + max-over-ranks timing, rank-0 JSON -- with two ranks on this one GPU over gloo
+    (RCCL needs a GPU per rank; the driver runs that).  Strong scaling (the default) splits ONE 4096-row
+    minibatch, so the summed objective after the same number of steps must equal the single-rank run's."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    one = _bench_line(1, [], 0)
+    two = _bench_line(2, [], _free_port())
+    assert one['n_gpus'] == 1 and two['n_gpus'] == 2
+    assert one['scaling'] == 'strong' and two['scaling'] == 'strong'
+    assert two['config']['global_batch'] == 4096 and two['config']['per_gpu_batch'] == 2048
+    for r in (one, two):
+        assert r['metric'] == 'dsvi_elbo_steps_per_sec' and r['unit'] == 'steps/s' and r['steps'] == 3
+        assert r['value'] == pytest.approx(r['iterations_per_sec'])        # strong: value IS iterations/s
+        assert r['rows_per_sec'] == pytest.approx(4096 * r['iterations_per_sec'], rel=1e-3)
+        assert 'roofline' in r and r['roofline']['bound'] == 'mfma'
+    assert two['final_loss'] == pytest.approx(one['final_loss'], rel=2e-4)
+    weak = _bench_line(2, ['--scaling', 'weak'], _free_port())
+    assert weak['scaling'] == 'weak' and weak['config']['global_batch'] == 8192
+    assert weak['value'] == pytest.approx(2 * weak['iterations_per_sec'], rel=1e-3)
