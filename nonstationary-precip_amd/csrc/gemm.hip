@@ -114,18 +114,8 @@ struct TileLoader {
     const T* cur;                                             // fast-path pointer of piece 0 at the current K-tile
     int64_t pstep, kstep;                                     // element strides: between pieces, per k
     __device__ __forceinline__ void init(int tid, const T* base, int64_t row0, int64_t sr, int64_t sk, int64_t kbeg) {
-        if (MODE == 0) {
-            if (sizeof(T) == 8) {
-                // 8-byte elements: the k-major LDS image has a row stride = 0 mod 128 B (what the conflict-free
-                // ds_read_b64 fragments need), so the lanes of one ds_write_b64 must differ in their ROW: 16 consecutive
-                // lanes take 16 consecutive rows (one 128-B run), the lane groups of a wave take the k chunks.  (Rows
-                // by tid / TPK put four k chunks of four rows on the same 32 bytes: 4-way conflicts, 8 % of wave cycles.)
-                constexpr int RPW = 64 / TPK;                  // rows per wave
-                r0 = (tid >> 6) * RPW + (tid & 63) % RPW; k0 = ((tid & 63) / RPW) * 4;
-            } else {
-                r0 = tid / TPK; k0 = (tid % TPK) * 4;
-            }
-        } else { r0 = (tid % TPR) * 4; k0 = tid / TPR; }
+        if (MODE == 0) { r0 = tid / TPK; k0 = (tid % TPK) * 4; }
+        else { r0 = (tid % TPR) * 4; k0 = tid / TPR; }
         kstep = sk;
         pstep = MODE == 0 ? RS * sr : KS * sk;
         cur = base + (row0 + r0) * sr + (kbeg + k0) * sk;

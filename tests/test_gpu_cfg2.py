@@ -7,8 +7,11 @@ inducing locations (SGPR / Titsias objective).
 
 * all 5,676 rows, M = 512, float32: objective + gradients finite, a few Adam steps decrease it, predictions finite --
   the oracle's (N, N, 2, 2) temporaries do not fit at this size;
-* a 900-row training subset + 150 test rows, M = 512: objective, posterior mean and variance against the CPU oracle
-  (oracle.psgibbs + oracle.sparse.ipk_*), float32 model vs float64 oracle, tolerances at the asserts."""
+* a 900-row training subset + 150 test rows against the CPU oracle (oracle.psgibbs + oracle.sparse.ipk_*), float32 model
+  vs float64 oracle, tolerances at the asserts.  Here the inducing locations are a 6 x 6 lattice: with 512 locations on
+  this smooth kernel Kzz is numerically singular and BOTH the reference (psd_safe_cholesky) and this path only factor
+  it after adding jitter at a precision-dependent retry level, so a 512-point comparison would test the jitter ladder,
+  not the arithmetic."""
 import math
 import os
 
@@ -105,11 +108,15 @@ def test_sparse_multivariate_gibbs_gp_matches_oracle_on_a_subset(data_dir):
     xj = x + 0.02 * torch.randn(x.shape, generator=g)
     tr, te = idx[:900], idx[900:1050]
     xtr, ytr, xte = xj[tr], y[tr], xj[te]
-    Z = _inducing(x)
+    u = torch.linspace(-1.8, 1.8, 6)
+    Z = torch.stack(torch.meshgrid(u, u, indexing='ij'), -1).reshape(-1, 2) + 0.05 * torch.randn(36, 2, generator=g)
     model, lik = _model(xtr, ytr, Z)
     model.train(); lik.train()
     mll = gpytorch.mlls.ExactMarginalLogLikelihood(lik, model)
-    val = mll(model(model.train_inputs[0]), model.train_targets)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')                       # no psd_safe jitter retry may be involved in a parity case
+        val = mll(model(model.train_inputs[0]), model.train_targets)
     val.backward()
     k = model.covar_module.base_kernel.base_kernel
     assert k.D.grad is not None and bool(torch.isfinite(k.D.grad).all())
