@@ -133,6 +133,12 @@ def test_sparse_multivariate_gibbs_gp_matches_oracle_on_a_subset(data_dir):
     Kzz, Kxz, Ksz = K(Zd, Zd), K(xd, Zd), K(xsd, Zd)
     kd_x, kd_s = os_ * torch.ones(len(xd), dtype=F64), os_ * torch.ones(len(xsd), dtype=F64)   # PS kernel diagonal is 1
     ref = sparse.ipk_mll(Kzz, Kxz, kd_x, yd, noise)
+    # + the registered matrix-normal prior on H (sparse_multivariate_gibbs_kernel.py:58-62: static row covariance of
+    # Z_init under the row kernel, identity column covariance); ExactMarginalLogLikelihood adds log p(H) / N
+    from oracle import kernels as OKk
+    row = OKk.rbf_ard(Z.float(), Z.float(), torch.full((1, 2), math.log(2.0)), math.log(2.0))      # float32, as built
+    prior = psgibbs.MatrixNormalPrior(torch.zeros(36, 2), row, torch.eye(2))
+    ref = ref + prior.log_prob(H.float()) / len(xd)
     # float32 kernel build + float32 M x M Cholesky of a kernel matrix with near-duplicate inducing points
     assert abs(float(val) - float(ref)) < 5e-3 * abs(float(ref)), (float(val), float(ref))
     model.eval(); lik.eval()
