@@ -23,6 +23,13 @@
 #include <type_traits>
 #include "common.h"
 
+#ifndef NSGP_F64ACC_BN
+#define NSGP_F64ACC_BN 64
+#endif
+#ifndef NSGP_F64ACC_BK
+#define NSGP_F64ACC_BK 16
+#endif
+
 namespace {
 
 template <typename T> struct Mfma;
@@ -160,7 +167,7 @@ struct TileLoader {
 // cancel to O(1); tools/probes/whiten_precision.py), float64 accumulation reproduces the float64 solve to 3e-8.
 template <typename T, int BM, int BN, int BK, int MODE_A, int MODE_B, int EPI = 0, int KSC = 0, int PF = 0, int EDGE = 1,
           int MIX = 0>
-__global__ __launch_bounds__(256, (BM == 128 && BN == 64 && sizeof(T) == 4) ? 3 : 2) void gemm_kernel(GemmArgs g, T alpha, const T* __restrict__ A,
+__global__ __launch_bounds__(256, (BM == 128 && BN == 64 && sizeof(T) == 4) ? 3 : ((sizeof(T) == 8 && BM == 128 && BK == 32) ? 1 : 2)) void gemm_kernel(GemmArgs g, T alpha, const T* __restrict__ A,
                                                    const T* __restrict__ B, T beta, T* __restrict__ C,
                                                    T* __restrict__ slabs, Epi ep) {
     static_assert(MIX == 0 || (sizeof(T) == 8 && EPI == 1 && KSC == 0 && PF == 0), "MIX: float64 colstats projection only");
@@ -934,7 +941,7 @@ int tri_gemm_colstats_f64acc_impl(const double* W, const float* X, const float* 
     if (!W) return -1; if (!X) return -2; if (batch < 0) return -4; if (M < 0) return -5; if (n < 0) return -6;
     if (!Y) return -7; if (!part_sq) return -9;
     if (batch == 0 || M == 0 || n == 0) return 0;
-    constexpr int BM_ = 128, BN_ = 64, BK_ = 16;
+    constexpr int BM_ = 128, BN_ = NSGP_F64ACC_BN, BK_ = NSGP_F64ACC_BK;
     if (part_rows < cdiv64(M, BM_)) return -10;
     GemmArgs g{};
     g.M = M; g.N = n; g.K = M;
@@ -958,12 +965,15 @@ int tri_gemm_colstats_f64acc_impl(const double* W, const float* X, const float* 
     // the kernel takes its B / C pointers as double* and reinterprets them (MIX = 1)
     const double* Bp = reinterpret_cast<const double*>(X);
     double* Cp = reinterpret_cast<double*>(Y);
-    if (whole)
+    if (whole) {
+        nsgp_opt_in_lds((const void*)gemm_kernel<double, BM_, BN_, BK_, 0, 1, 1, 0, 0, 0, 1>, lds);
         hipLaunchKernelGGL((gemm_kernel<double, BM_, BN_, BK_, 0, 1, 1, 0, 0, 0, 1>), grid, dim3(256), lds, st, g, 1.0, W, Bp,
                            0.0, Cp, (double*)nullptr, ep);
-    else
+    } else {
+        nsgp_opt_in_lds((const void*)gemm_kernel<double, BM_, BN_, BK_, 0, 1, 1, 0, 0, 1, 1>, lds);
         hipLaunchKernelGGL((gemm_kernel<double, BM_, BN_, BK_, 0, 1, 1, 0, 0, 1, 1>), grid, dim3(256), lds, st, g, 1.0, W, Bp,
                            0.0, Cp, (double*)nullptr, ep);
+    }
     return nsgp_launch_status();
 }
 }  // namespace
