@@ -530,7 +530,13 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && sizeof(T) == 4) ? 3 
             sstore(0, ra0, rb0);
             __syncthreads();
             generic_tiles(0, h0);
-            if (h1 > h0) {
+            // float64 tiles are short (BK = 16: 2048 MFMA cycles per K-tile, the staging stores start after 1024): a load
+            // issued at the top of a tile has not landed when its first store comes up (wait_any 20 % of wave time).
+            // DEPTH2 keeps TWO K-tiles of loads in flight in two register sets: tile t stores the set loaded during tile
+            // t - 1 and issues the loads of tile t + 2.
+            constexpr bool DEPTH2 = sizeof(T) == 8 && KSC == 0;
+            int hend = h0;                                                   // first tile the hot loop did NOT run
+            if (!DEPTH2 && h1 > h0) {
                 const T* pa = la.cur + (int64_t)(h0 + 1) * BK * la.kstep;
                 const TB* pb = lb.cur + (int64_t)(h0 + 1) * BK * lb.kstep;
                 const int64_t da = (int64_t)BK * la.kstep, db = (int64_t)BK * lb.kstep;
@@ -544,8 +550,44 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && sizeof(T) == 4) ? 3 
                     ktile(t & 1, true, std::integral_constant<int, FULLMASK>{}, std::false_type{}, ra0, rb0);
                     __syncthreads();
                 }
+                hend = h1;
             }
-            generic_tiles(h1 > h0 ? h1 : h0, nt);
+            if constexpr (DEPTH2) {
+                // tiles t of [h0, h2): t + 1 and t + 2 regular.  Pairs of tiles, so the register sets alternate statically.
+                const int h2 = h1 - 1;
+                if (h2 - h0 >= 2) {
+                    Frag4<T> rax[PA];
+                    Frag4<TB> rbx[PB];
+                    const T* pa = la.cur + (int64_t)(h0 + 1) * BK * la.kstep;
+                    const TB* pb = lb.cur + (int64_t)(h0 + 1) * BK * lb.kstep;
+                    const int64_t da = (int64_t)BK * la.kstep, db = (int64_t)BK * lb.kstep;
+#pragma unroll
+                    for (int p = 0; p < PA; ++p) ra0[p] = ldg4(pa + p * la.pstep);                  // tile h0 + 1 -> set 0
+#pragma unroll
+                    for (int p = 0; p < PB; ++p) rb0[p] = ldg4(pb + p * lb.pstep);
+                    pa += da; pb += db;
+                    const int npairs = (h2 - h0) / 2;
+                    int t = h0;
+                    for (int q = 0; q < npairs; ++q, t += 2) {
+#pragma unroll
+                        for (int p = 0; p < PA; ++p) rax[p] = ldg4(pa + p * la.pstep);              // tile t + 2 -> set 1
+#pragma unroll
+                        for (int p = 0; p < PB; ++p) rbx[p] = ldg4(pb + p * lb.pstep);
+                        pa += da; pb += db;
+                        ktile(t & 1, true, std::integral_constant<int, FULLMASK>{}, std::false_type{}, ra0, rb0);   // stores t + 1
+                        __syncthreads();
+#pragma unroll
+                        for (int p = 0; p < PA; ++p) ra0[p] = ldg4(pa + p * la.pstep);              // tile t + 3 -> set 0
+#pragma unroll
+                        for (int p = 0; p < PB; ++p) rb0[p] = ldg4(pb + p * lb.pstep);
+                        pa += da; pb += db;
+                        ktile((t + 1) & 1, true, std::integral_constant<int, FULLMASK>{}, std::false_type{}, rax, rbx);   // stores t + 2
+                        __syncthreads();
+                    }
+                    hend = t;           // LDS holds tile `hend`; set 0's prefetch of tile hend + 1 is dropped (reloaded below)
+                }
+            }
+            generic_tiles(hend, nt);
         }
     }
 
