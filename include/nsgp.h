@@ -241,6 +241,27 @@ size_t nsgp_svgp_f64acc_tiles(int64_t M);
 int nsgp_svgp_tri_gemm_colstats_f64acc(const double* W, const float* X, const float* rowvec, int64_t batch, int64_t M,
                                        int64_t n, float* Y, float* part_dot, float* part_sq, int64_t part_rows,
                                        void* stream);
+/* "bf16 forward" of BASELINE configs[4] (3-layer DSVI DeepGP, M = 2048: bf16 forward / fp32 Cholesky panels): the two
+ * forward projections A = W Kzx, C = Lq^T A of a whitened SVGP layer (gpytorch VariationalStrategy.forward behind
+ * /root/reference/models/dgps.py:44-51, driven by :92-98) on v_mfma_f32_32x32x16_bf16 -- bf16 operands, float32
+ * accumulation and outputs -- csrc/gemm_bf16.hip.  All bf16 buffers are passed as void* (2-byte elements).
+ *   nsgp_svgp_tri_gemm_colstats_bf16: Y[b] = P[b] Qt[b]^T with P (M x M) bf16 triangular (tri = 1: lower, k <= m;
+ *       tri = 2: upper, k >= m; the zeros are in memory), Qt (n x M) bf16 (k contiguous); Y float32 (M x n); YT:
+ *       optional bf16 transposed copy of Y (n x M), the Qt operand of the next product; part_dot / part_sq: the
+ *       column-statistic partials of nsgp_svgp_tri_gemm_colstats (float32, ceil(M / 128) tile rows = nsgp_svgp_bf16_tiles).
+ *   nsgp_cast_sq_bf16_{f32,f64}: dst (b, n, n) bf16 <- src, optionally transposed and / or lower triangle only.
+ *   nsgp_rbf_build_t_bf16: Kxz[b][i][k] = bf16(os[b] RBF-ARD(x_i, z[b][k]; ls[b])), the transpose of Kzx, k contiguous
+ *       (z:(b,M,D) x:(n,D) shared [sxb = 0] or (b,n,D) [sxb = n D]).
+ *   nsgp_transpose_cast_bf16: dst (b, n, M) bf16 <- transpose of src (b, M, n) float32 (A -> the Qt operand of product 2
+ *       when product 1 ran in float32 / float64). */
+size_t nsgp_svgp_bf16_tiles(int64_t M);
+int nsgp_transpose_cast_bf16(const float* src, void* dst, int64_t batch, int64_t M, int64_t n, void* stream);
+int nsgp_svgp_tri_gemm_colstats_bf16(const void* P, int tri, const void* Qt, const float* rowvec, int64_t batch, int64_t M,
+                                     int64_t n, float* Y, void* YT, float* part_dot, float* part_sq, void* stream);
+int nsgp_cast_sq_bf16_f32(const float* src, void* dst, int64_t n, int64_t batch, int transpose, int tril, void* stream);
+int nsgp_cast_sq_bf16_f64(const double* src, void* dst, int64_t n, int64_t batch, int transpose, int tril, void* stream);
+int nsgp_rbf_build_t_bf16(const float* z, const float* x, const float* ls, const float* os, int64_t batch, int64_t M,
+                          int64_t n, int64_t D, int64_t sxb, void* out, void* stream);
 int nsgp_svgp_colstats_finalize_f32(const float* part_dot, const float* part_sq_a, const float* part_sq_c,
                                     const float* base, int64_t batch, int64_t tiles, int64_t n, float* mean,
                                     float* var, void* stream);

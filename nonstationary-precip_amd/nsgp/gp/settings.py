@@ -115,6 +115,19 @@ class chol_bwd_f64(_feature_flag):
     _state = True
 
 
+class forward_precision(_value_context):
+    """'f32' (default): the forward projections A = W Kzx, C = Lq^T A of a float32 SVGP layer run in float32 (A accumulated
+    in float64 under settings.whiten_matmul_f64).
+    'bf16': BASELINE configs[4]'s "bf16 forward" where bf16 can carry it -- C = Lq^T A (O(1) operands) on
+    v_mfma_f32_32x32x16_bf16 (bf16 operands, float32 accumulation; csrc/gemm_bf16.hip) from a bf16 transposed copy of A;
+    A itself stays float32 / float64-accumulated.  The posterior mean is untouched, the variance carries bf16 rounding.
+    'bf16_all': both projections in bf16, Kxz emitted in bf16 by the build kernel -- configs[4] to the letter.  W = L^-1 has
+    entries ~1e2 whose products cancel to O(1): with 8-bit mantissas the layer outputs are off by O(1) at M = 2048
+    (tests/test_gpu_bf16.py prints the measured error) -- a throughput figure only.
+    Backward, Cholesky and the objective stay float32 / float64 in every mode."""
+    _global_value = 'f32'
+
+
 class whiten_matmul_f64(_feature_flag):
     """On (default): the whitened projection A = L^-1 Kzx of a float32 SVGP layer is accumulated in float64 (float64 MFMA
     on the float32 Kzx, rounded once) -- what the reference computes (a float64 triangular solve cast back).

@@ -523,6 +523,91 @@ def svgp_project(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None):
     return A, C, mean, var
 
 
+def svgp_project_bf16(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None, kernel_inputs=None):
+    """BASELINE configs[4]'s "bf16 forward": the forward projections of a float32 SVGP layer with bf16 matrix-core products
+    (bf16 operands, float32 accumulation, float32 A / C; csrc/gemm_bf16.hip), column statistics in the epilogues.
+
+    kernel_inputs=None (settings.forward_precision('bf16')): A = W Kzx runs as in `svgp_project` (float32, or float64
+        accumulation with W64f) -- its terms |W||Kzx| ~ 1e2 cancel to O(1), which bf16 operands cannot carry (measured at
+        M = 2048: 160 % error on the layer outputs) -- and C = Lq^T A, whose operands are O(1), runs on the bf16 cores from a
+        bf16 transposed copy of A.
+    kernel_inputs=(Z, x, ls, os) (forward_precision('bf16_all')): BOTH products in bf16, Kxz written in bf16 by the build
+        kernel (nsgp_rbf_build_t_bf16) -- configs[4] to the letter; a throughput figure, not a usable numerical mode.
+    Returns A, C, mean, var (float32).  M must be a multiple of 8."""
+    ref = _chk(Kzx, Lq, m, base)
+    if ref.dtype != torch.float32:
+        raise BackendError('svgp_project_bf16: float32 layers only')
+    Kzx, Lq, m, base = _c(Kzx), _c(Lq), _c(m), _c(base.reshape(-1))
+    batch, M, n = Kzx.shape
+    if M % 8 != 0:
+        raise BackendError('svgp_project_bf16: M must be a multiple of 8')
+    if Lq.shape != (batch, M, M) or m.shape != (batch, M) or base.shape != (batch,):
+        raise BackendError('svgp_project_bf16: shapes')
+    lib = _lib.load()
+    st = _stream()
+    bf = torch.bfloat16
+    Ub = torch.empty((batch, M, M), dtype=bf, device=ref.device)
+    AT = torch.empty((batch, n, M), dtype=bf, device=ref.device)
+    _lib.call('nsgp_cast_sq_bf16_f32', _p(Lq), _p(Ub), M, batch, 1, 1, st)          # tril(Lq)^T
+    T = int(lib.nsgp_svgp_bf16_tiles(M))                                              # 128-row tiles
+    C = torch.empty((batch, M, n), dtype=ref.dtype, device=ref.device)
+    flops = 1.0 * M * M * n * batch
+    if kernel_inputs is None:
+        # product 1 at full precision; its partials use the float32 plan's tile rows (>= T)
+        Tf = int(lib.nsgp_svgp_colstats_tiles(M, n, batch, 4))
+        if Tf < T:
+            raise BackendError('svgp_project_bf16: tile-row mismatch')
+        A = torch.empty_like(Kzx)
+        part = torch.zeros((3, batch, max(Tf, 1), n), dtype=ref.dtype, device=ref.device) if Tf > T else \
+            torch.empty((3, batch, max(Tf, 1), n), dtype=ref.dtype, device=ref.device)
+        W = _c(W)
+        if W64f is not None:
+            _timed(lambda: _lib.call('nsgp_svgp_tri_gemm_colstats_f64acc', _p(_c(W64f)), _p(Kzx), _p(m), batch, M, n, _p(A),
+                                     _p(part[0]), _p(part[1]), Tf, st), flops, 'f64acc')
+        else:
+            _timed(lambda: _lib.call('nsgp_svgp_tri_gemm_colstats_f32', _p(W), 0, _p(Kzx), _p(m), batch, M, n, _p(A),
+                                     _p(part[0]), _p(part[1]), st), flops, ref.dtype)
+        _lib.call('nsgp_transpose_cast_bf16', _p(A), _p(AT), batch, M, n, st)
+        if Tf != T:
+            # the bf16 kernel lays its partials out with its own tile-row count: give it a compact buffer, then widen
+            p2 = torch.empty((batch, T, n), dtype=ref.dtype, device=ref.device)
+            _timed(lambda: _lib.call('nsgp_svgp_tri_gemm_colstats_bf16', _p(Ub), 2, _p(AT), None, batch, M, n, _p(C), None,
+                                     None, _p(p2), st), flops, 'bf16')
+            part[2, :, :T].copy_(p2)
+        else:
+            _timed(lambda: _lib.call('nsgp_svgp_tri_gemm_colstats_bf16', _p(Ub), 2, _p(AT), None, batch, M, n, _p(C), None,
+                                     None, _p(part[2]), st), flops, 'bf16')
+        T = Tf
+    else:
+        Z, x, ls, os_ = kernel_inputs
+        Z, ls, os_ = _c(Z), _c(ls), _c(os_.reshape(-1))
+        D = Z.shape[-1]
+        x = _c(x)
+        sxb = 0 if x.dim() == 2 else x.shape[1] * D
+        Wsrc = _c(W64f) if W64f is not None else _c(W)
+        Wb = torch.empty((batch, M, M), dtype=bf, device=ref.device)
+        Kxz = torch.empty((batch, n, M), dtype=bf, device=ref.device)
+        _lib.call('nsgp_cast_sq_bf16_f64' if Wsrc.dtype == torch.float64 else 'nsgp_cast_sq_bf16_f32', _p(Wsrc), _p(Wb), M,
+                  batch, 0, 1, st)
+        _lib.call('nsgp_rbf_build_t_bf16', _p(Z), _p(x), _p(ls), _p(os_), batch, M, n, D, sxb, _p(Kxz), st)
+        part = torch.empty((3, batch, max(T, 1), n), dtype=ref.dtype, device=ref.device)
+        A = torch.empty_like(Kzx)
+        _timed(lambda: _lib.call('nsgp_svgp_tri_gemm_colstats_bf16', _p(Wb), 1, _p(Kxz), _p(m), batch, M, n, _p(A), _p(AT),
+                                 _p(part[0]), _p(part[1]), st), flops, 'bf16')
+        _timed(lambda: _lib.call('nsgp_svgp_tri_gemm_colstats_bf16', _p(Ub), 2, _p(AT), None, batch, M, n, _p(C), None,
+                                 None, _p(part[2]), st), flops, 'bf16')
+    mean = torch.empty((batch, n), dtype=ref.dtype, device=ref.device)
+    var = torch.empty_like(mean)
+    if affine is None:
+        xa = w = c = None
+        sxa = Da = swb = scb = 0
+    else:
+        xa, sxa, Da, w, swb, c, scb = _affine_args(affine, batch, n, ref)
+    _lib.call('nsgp_svgp_colstats_finalize_affine_f32', _p(part[0]), _p(part[1]), _p(part[2]), _p(base), float(base_add),
+              batch, T, n, _p(xa), sxa, Da, _p(w), swb, _p(c), scb, _p(mean), _p(var), st)
+    return A, C, mean, var
+
+
 def svgp_project_bwd(Lq, m, A, C, gmean, gvar, affine=None):
     """Adjoints of svgp_project w.r.t. A (total, through C as well), Lq and m:
     Abar = 2 (Lq C) diag(gvar) + m gmean^T - 2 A diag(gvar);  Lqbar = tril(A diag(2 gvar) C^T);  mbar = A gmean.

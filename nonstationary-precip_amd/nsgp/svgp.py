@@ -170,11 +170,17 @@ class SVGPLayerFn(torch.autograd.Function):
         if W64f is None and W64.dtype == torch.float64 and x.dtype == torch.float32:
             W64f = W64
         from .gp import settings
-        if x.dtype != torch.float32 or not settings.whiten_matmul_f64.on():
+        if x.dtype != torch.float32 or not (settings.whiten_matmul_f64.on() or settings.forward_precision.value() == 'bf16_all'):
             W64f = None
-        Kzx = ops.rbf_build(Z, x, ls, os_)                                       # (b,M,n)
+        Kzx = ops.rbf_build(Z, x, ls, os_)                                       # (b,M,n)  (the backward needs it in float32)
         affine = None if (mean_w is None and mean_c is None) else (x, mean_w, mean_c)
-        A, C, mean, var = ops.svgp_project(W, Kzx, Lq, m, os_, base_add=VAR_JITTER, affine=affine, W64f=W64f)   # 2 GEMMs
+        fp = settings.forward_precision.value()
+        if x.dtype == torch.float32 and fp in ('bf16', 'bf16_all') and Z.shape[-2] % 8 == 0:
+            # BASELINE configs[4]'s "bf16 forward": C = Lq^T A on the bf16 matrix cores; 'bf16_all' also A = W Kzx
+            A, C, mean, var = ops.svgp_project_bf16(W, Kzx, Lq, m, os_, base_add=VAR_JITTER, affine=affine, W64f=W64f,
+                                                    kernel_inputs=(Z, x, ls, os_) if fp == 'bf16_all' else None)
+        else:
+            A, C, mean, var = ops.svgp_project(W, Kzx, Lq, m, os_, base_add=VAR_JITTER, affine=affine, W64f=W64f)   # 2 GEMMs
         ctx.save_for_backward(x, Z, ls, os_, m, Lq, W, Kzx, A, C, mean_w, mean_c)
         ctx.w_dtype = W64.dtype
         return mean, var
