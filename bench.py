@@ -366,12 +366,36 @@ def gibbs_map_step_ms(device, n):
     return round(e0.elapsed_time(e1) / 3, 3)
 
 
+def main_cfg5(args):
+    """BASELINE configs[4] on one GPU as a bench.py line (single process; the 8-GPU form of this config shares the
+    data-parallel path of the headline config)."""
+    if int(os.environ.get('WORLD_SIZE', '1')) != 1:
+        raise SystemExit('--config cfg5 is a single-GPU run')
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import dsvi_cfg5_probe as probe
+    torch.cuda.set_device(0)
+    pa = probe.parser().parse_args(['--steps', str(args.steps), '--warmup', str(args.warmup), '--forward', args.forward])
+    r = probe.run(pa)
+    print(json.dumps({'metric': 'dsvi_elbo_steps_per_sec', 'value': r['steps_per_sec'], 'unit': 'steps/s', 'n_gpus': 1,
+                      'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': r['ms_per_step'], 'higher_is_better': True,
+                      'scaling': 'strong', 'vs_baseline': None,
+                      'dtype': 'f32' if args.forward == 'f32' else 'f32 (bf16 forward projections: ' + args.forward + ')',
+                      'data': 'synthetic', 'config': {'workload': r['workload'], 'M': 2048, 'S': 10, 'global_batch': 4096,
+                                                      'N': 1000000, 'parallelism': 'dp1', 'forward': args.forward},
+                      'detail': r}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--config', choices=('cfg4', 'cfg5'), default='cfg4',
+                    help='cfg4 (default): BASELINE configs[3], the headline 2-layer M=1024 workload; cfg5: configs[4], the 3-layer '
+                         'M=2048 N=1e6 shape on ONE GPU (tools/dsvi_cfg5_probe.py), see --forward')
+    ap.add_argument('--forward', choices=('f32', 'bf16', 'bf16_all'), default='f32',
+                    help="cfg5 only: settings.forward_precision -- configs[4]'s bf16 forward")
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly (no hipGraph replay)')
     ap.add_argument('--no-build-chol', action='store_true',
                     help='skip the Gibbs-build + Cholesky fields (PMC passes of the DSVI step only)')
@@ -388,6 +412,8 @@ def main():
                          '"analysis" and is not a result for --gpus G.')
     args = ap.parse_args()
 
+    if args.config == 'cfg5':
+        return main_cfg5(args)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))

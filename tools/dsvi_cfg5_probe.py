@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""DSVI step time of BASELINE configs[4]'s shape on ONE MI355X, float32 (the config's bf16 operand path is not built):
+"""DSVI step time of BASELINE configs[4]'s shape on ONE MI355X (float32, or the config's "bf16 forward" with --forward):
 3-layer DeepGP = DeepGP(num_layers=2) (tied hidden layer 3->3 applied twice + last 3->1, so num_output_dims = 3),
 M=2048 inducing points, synthetic N=1e6 rows on a 100^3 grid, minibatch 4096, S=10; forward + ELBO + backward + Adam
 captured as one hipGraph, like bench.py.  Not a bench.py line (that is configs[3]); prints one JSON line.
 
-    python tools/dsvi_cfg5_probe.py [--steps 10] [--warmup 3] [--M 2048]
+    python tools/dsvi_cfg5_probe.py [--steps 10] [--warmup 3] [--M 2048] [--forward f32|bf16|bf16_all] [--no-f64acc]
+    python bench.py --config cfg5 [--forward bf16]          # the same run as a bench.py JSON line
 """
 import argparse
 import json
@@ -18,15 +19,8 @@ import torch  # noqa: E402
 from bench import GemmTimer, MFMA_F32_PEAK_TFLOPS  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--M', type=int, default=2048)
-    ap.add_argument('--batch', type=int, default=4096)
-    ap.add_argument('--samples', type=int, default=10)
-    args = ap.parse_args()
-    dev = torch.device('cuda', 0)
+def run(args):
+    dev = torch.device('cuda', torch.cuda.current_device())
     import models.dgps as dgps
     from nsgp import ops
     from nsgp.dist import PhiloxEps
@@ -66,7 +60,8 @@ def main():
         opt.step(gather=False)
         return loss.detach()
 
-    with settings.num_likelihood_samples(S), settings.eps_provider(eps):
+    with settings.num_likelihood_samples(S), settings.eps_provider(eps), settings.forward_precision(args.forward), \
+            settings.whiten_matmul_f64(not args.no_f64acc):
         x_in.copy_(xs[0]); y_in.copy_(ys[0])
         with torch.no_grad():
             model(x_in)
@@ -85,16 +80,40 @@ def main():
         whole_step()
         ms32, fl32, n32 = timer.summary(torch.float32)
         ms64, fl64, n64 = timer.summary(torch.float64)
+        msacc, flacc, nacc = timer.summary('f64acc')
+        msbf, flbf, nbf = timer.summary('bf16')
         ops.set_gemm_timer(None)
-    print(json.dumps({
+    return {
         'workload': f'3-layer DSVI DeepGP (tied 3->3 hidden x2 + last 3->1), M={args.M}, S={S}, minibatch {B}, '
-                    f'synthetic N={N} 3-D grid; fwd+ELBO+bwd+Adam, float32 with float64 Kzz Cholesky',
+                    f'synthetic N={N} 3-D grid; fwd+ELBO+bwd+Adam, float32 with float64 Kzz Cholesky; forward '
+                    f'projections: {args.forward}' + ('' if args.no_f64acc else ' (A accumulated in float64)'),
+        'forward': args.forward, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(el / args.steps * 1e3, 2), 'steps_per_sec': round(args.steps / el, 2),
         'loss_first': round(float(losses[0]), 4), 'loss_last': round(float(losses[-1]), 4),
         'f32_gemm_ms_per_step': round(ms32, 2), 'f32_gemm_TFLOPs': round(fl32 / (ms32 * 1e-3) / 1e12, 1),
         'f32_gemm_frac_of_peak': round(fl32 / (ms32 * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 3),
         'f32_gemm_launches': n32, 'f64_gemm_ms_per_step': round(ms64, 2), 'f64_gemm_launches': n64,
-        'hbm_peak_allocated_GB': round(torch.cuda.max_memory_allocated() / 1e9, 2)}))
+        'f64acc_gemm_ms_per_step': round(msacc, 2), 'f64acc_gemm_launches': nacc,
+        'f64acc_gemm_TFLOPs': round(flacc / (msacc * 1e-3) / 1e12, 1) if nacc else None,
+        'bf16_gemm_ms_per_step': round(msbf, 2), 'bf16_gemm_launches': nbf,
+        'bf16_gemm_TFLOPs': round(flbf / (msbf * 1e-3) / 1e12, 1) if nbf else None,
+        'hbm_peak_allocated_GB': round(torch.cuda.max_memory_allocated() / 1e9, 2)}
+
+
+def parser():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--M', type=int, default=2048)
+    ap.add_argument('--batch', type=int, default=4096)
+    ap.add_argument('--samples', type=int, default=10)
+    ap.add_argument('--forward', choices=('f32', 'bf16', 'bf16_all'), default='f32')
+    ap.add_argument('--no-f64acc', action='store_true', help='float32 accumulation of A = W Kzx (round-1 arithmetic)')
+    return ap
+
+
+def main():
+    print(json.dumps(run(parser().parse_args())))
 
 
 if __name__ == '__main__':
