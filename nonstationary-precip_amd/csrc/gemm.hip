@@ -860,7 +860,11 @@ int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam,
     if (epi) ep = *epi;
     if (tiles_m_out) *tiles_m_out = g.tiles_m;
     const int ekind = ep.kind, eks = ep.ks != nullptr;
-    const bool one_round = ngrid * nb * g.ksplit <= 256 * 3;      // f64: latency-bound single-round grids take PF = 1
+    // The round-1 "two register sets, old loop" variant (PF = 1) for single-round float64 grids is no longer selected: the
+    // software-pipelined loop with two K-tiles of loads in flight measures the same (tools/potrf_bench.py: 3 x 1024^3
+    // Cholesky adjoint 384 vs 400 us).  NSGP_GEMM_PF=1 selects it for A/B timing.
+    const char* pfe = getenv("NSGP_GEMM_PF");
+    const bool one_round = (pfe && pfe[0] == '1') && ngrid * nb * g.ksplit <= 256 * 3;
     if (ekind != 0 && (g.ksplit != 1 || beta != T(0) || (flags & NSGP_GEMM_C_LOWER))) return -30;
     const int64_t bnn = p.narrow ? 64 : bmn, bkk = (bmn == 128 ? 32 : 16);
     // whole, vector-loadable tiles everywhere -> the variant without bounds code (EDGE = 0)

@@ -31,3 +31,16 @@ L, info = ops.potrf(K)
 print('info', info.tolist())
 print(f'potrf  {timeit(lambda: ops.potrf(K)):8.1f} us')
 print(f'trtri  {timeit(lambda: ops.trtri(L)):8.1f} us')
+# Cholesky adjoint of the whitening chain (three float64 M x M x M triangular products, WhitenFn.backward)
+W = ops.trtri(L)
+Wbar = torch.tril(torch.randn(b, M, M, generator=g, dtype=torch.float64)).cuda()
+
+
+def chol_bwd():
+    Bm = ops.gemm(Wbar, W, tb=True, flags=ops.GEMM_A_LOWER | ops.GEMM_B_UPPER)
+    S = ops.chol_bwd_phi_sym(Bm)
+    T = ops.gemm(S, W, flags=ops.GEMM_B_LOWER)
+    return ops.gemm(W, T, ta=True, alpha=-0.5, flags=ops.GEMM_A_UPPER)
+
+
+print(f'chol adjoint (3 GEMMs)  {timeit(chol_bwd):8.1f} us')
