@@ -76,14 +76,17 @@ class GemmTimer:
         return ms, sum(r[2] for r in recs), len(recs)
 
 
-def build(device, dp_world):
+def build(device, dp_world, stage_of_fn=None):
+    """`stage_of_fn(model, mll)` -> {id(p): exchange group} (staged backward, nsgp/stages.py): lays the flat gradient
+    bucket out by the backward stage that completes each parameter's gradient."""
     import models.dgps as dgps
     from nsgp.gp.mlls import DeepApproximateMLL, VariationalELBO
     from nsgp.optim import FusedAdam
     torch.manual_seed(SEED)
     model = dgps.DeepGP(1, (N_DATA, 3), num_inducing=M_INDUCING).to(device)
     mll = DeepApproximateMLL(VariationalELBO(model.likelihood, model, N_DATA))
-    opt = FusedAdam(model.parameters(), lr=0.01, capturable=True, grads_as_views=False)
+    stage_of = stage_of_fn(model, mll) if stage_of_fn is not None else None
+    opt = FusedAdam(model.parameters(), lr=0.01, capturable=True, grads_as_views=False, stage_of=stage_of)
     return model, mll, opt
 
 
@@ -406,6 +409,16 @@ def main():
     ap.add_argument('--split-graph', action='store_true',
                     help='analysis only (N=1): replay the step as the TWO graphs an N>1 run uses (forward+backward, then Adam) '
                          'with the eager gradient all-reduce call between them (a no-op at N=1), to price the split')
+    ap.add_argument('--no-overlap', action='store_true',
+                    help='N>1: ONE all-reduce of the whole gradient bucket after the backward pass (round-1 behaviour) instead '
+                         'of the staged backward whose per-stage all-reduces overlap with the rest of the backward')
+    ap.add_argument('--staged', action='store_true',
+                    help='analysis only (N=1): run the step through the staged backward of an N>1 run (one graph per exchange '
+                         'group, the all-reduces are no-ops at N=1), to price the staging')
+    ap.add_argument('--rehearse-rccl', action='store_true',
+                    help='analysis only (N=1): create a ONE-rank RCCL process group and issue every collective of the N>1 step '
+                         'through it (staged backward, asynchronous per-stage all-reduces between the graph replays), so the '
+                         'ProcessGroupNCCL / stream / hipGraph interplay is exercised on a one-GPU box')
     ap.add_argument('--rank-share', type=int, default=1, metavar='G',
                     help='analysis only: run ONE rank\'s share of a G-rank job on this GPU (rows [0, 4096/G) of every '
                          'minibatch, the objective scaled as on rank 0 of G; no collective).  The JSON line is marked '
@@ -423,7 +436,12 @@ def main():
     dev_index = local_rank % max(ndev, 1)          # (rehearsals on a 1-GPU box put every rank on cuda:0)
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
-    if world > 1:
+    rehearse = args.rehearse_rccl and world == 1
+    if rehearse:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29555')
+        os.environ['RANK'], os.environ['WORLD_SIZE'] = '0', '1'
+    if world > 1 or rehearse:
         backend = os.environ.get('NSGP_DIST_BACKEND', 'nccl')              # 'nccl' is RCCL on ROCm
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=device)
@@ -449,8 +467,28 @@ def main():
     xs = [x_all[i[lo:hi]].to(device) for i in idx]                           # resident in HBM
     ys = [y_all[i[lo:hi]].to(device) for i in idx]
 
-    model, mll, opt = build(device, world)
-    dp = DataParallel(opt.bucket)
+    # Staged backward (N > 1): the gradient exchange of a stage's parameters runs under the next stage's kernels
+    staged = (world > 1 and not args.no_overlap) or args.staged or rehearse
+    plan, groups = None, {}
+    MAX_GROUPS = 3                # last layer | hidden layers | whitening chain + hyper-parameters (a few KB)
+
+    def discover_stages(model, mll):
+        # one forward pass with the cuts in place; the assignment depends on the model's structure only
+        model.train()
+        with settings.num_likelihood_samples(S_SAMPLES), settings.eps_provider(PhiloxEps(SEED, row0=lo)), \
+                settings.backward_stages(plan), transform_cache():
+            loss = dp_objective(mll, model(xs[0]), ys[0], gbatch, world * share, negate=True)
+        params = [p for p in model.parameters() if p.requires_grad]
+        final = plan.final_stage_of(loss, params)
+        groups['n'] = min(plan.num_stages, MAX_GROUPS)
+        groups['stages'] = plan.num_stages
+        return {pid: min(k, groups['n'] - 1) for pid, k in final.items()}
+
+    if staged:
+        from nsgp.stages import BackwardStages
+        plan = BackwardStages()
+    model, mll, opt = build(device, world, discover_stages if staged else None)
+    dp = DataParallel(opt.bucket, force=rehearse)
     dp.broadcast_params()
     eps = PhiloxEps(SEED, row0=lo, step_dev=opt.step_dev)     # step counter lives on the device
     model.train()
@@ -472,6 +510,32 @@ def main():
     def adam_step():
         opt.step(gather=False)
 
+    held = {}
+
+    def stage_group_fn(gi):
+        # exchange group gi of the staged backward: group 0 = forward + ELBO + the loss's own backward stage
+        def fn():
+            if gi == 0:
+                eps.start_step(0, row0=lo)
+                opt.zero_grad()
+                with settings.backward_stages(plan), transform_cache():
+                    out = model(x_in)
+                    held['loss'] = dp_objective(mll, out, y_in, gbatch, world * share, negate=True)
+                plan.run_stage(0, held['loss'], one)
+            for k in range(1, plan.num_stages):
+                if min(k, groups['n'] - 1) == gi:
+                    plan.run_stage(k)
+            opt.bucket.gather_grads(gi)              # this group's gradients -> their contiguous range of the bucket
+            return held['loss'].detach() if gi == 0 else None
+        return fn
+
+    def exchange_fn(gi):
+        def fn():
+            dp.allreduce_stage(gi, gather=False)     # asynchronous: the next group's kernels run under it
+            if gi == groups['n'] - 1:
+                dp.wait_stages()
+        return fn
+
     def whole_step():
         loss = fwd_bwd()
         adam_step()
@@ -491,7 +555,12 @@ def main():
         if use_graph:
             from nsgp.graph import GraphedCallable
             p0 = opt.bucket.flat_p.detach().clone()      # graph warm-up / capture runs real steps: undo them below
-            if world == 1 and not args.split_graph:
+            if staged:
+                from nsgp.graph import GraphedSequence
+                g_seq = GraphedSequence([stage_group_fn(gi) for gi in range(groups['n'])],
+                                        [exchange_fn(gi) for gi in range(groups['n'])])
+                g_adam = GraphedCallable(adam_step, warmup=1)
+            elif world == 1 and not args.split_graph:
                 g_step = GraphedCallable(whole_step)                 # forward + ELBO + backward + Adam: one graph
             else:
                 g_fb = GraphedCallable(fwd_bwd)                      # all-reduce stays an eager RCCL call
@@ -507,7 +576,16 @@ def main():
         def step(k):
             # minibatch -> static buffers: one multi-tensor copy kernel (two hipMemcpyAsync blits cost 10 us each)
             torch._foreach_copy_([x_in, y_in], [xs[k % n_batches], ys[k % n_batches]])
-            if not use_graph:
+            if staged and use_graph:
+                loss = g_seq()[0]
+                g_adam()
+            elif staged:
+                for gi in range(groups['n']):
+                    out = stage_group_fn(gi)()
+                    loss = out if gi == 0 else loss
+                    exchange_fn(gi)()
+                adam_step()
+            elif not use_graph:
                 loss = fwd_bwd()
                 dp.allreduce_grads(gather=False)
                 adam_step()
@@ -573,6 +651,14 @@ def main():
             'iterations_per_sec': round(args.steps / elapsed, 3),
             'rows_per_sec': round(gbatch * args.steps / elapsed, 1),
             **({'analysis_split_graph': 'two graph replays per step, as in an N>1 run'} if args.split_graph else {}),
+            **({'analysis_rehearse_rccl': 'one-rank RCCL group, every collective of the N>1 step issued'} if rehearse else {}),
+            **({'gradient_exchange': {
+                'mode': 'staged backward: per-stage sum-all-reduce overlapped with the following stage',
+                'backward_stages': groups['stages'], 'exchange_groups': groups['n'],
+                'group_bytes': [4 * (opt.bucket.segments[g][1] - opt.bucket.segments[g][0]) if g in opt.bucket.segments else 0
+                                for g in range(groups['n'])]}} if staged else
+               ({'gradient_exchange': {'mode': 'one sum-all-reduce of the flat bucket after the backward pass',
+                                       'group_bytes': [4 * opt.bucket.numel]}} if world > 1 else {})),
             **({'analysis': f'one rank\'s share of a {share}-rank job (rows [0, {hi - lo}) of each minibatch), '
                             'no collective; NOT a --gpus result'} if share > 1 else {}),
             'final_loss': round(final_loss, 5),
@@ -609,7 +695,7 @@ def main():
                 result['speedup_vs_cpu'] = round(result['value'] / v, 1)
                 result['speedup_vs_cpu_no_mirror'] = round(result['value'] / v2, 1)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if world > 1 or rehearse:
         dist.barrier()
         dist.destroy_process_group()
 

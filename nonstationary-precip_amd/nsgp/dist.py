@@ -65,18 +65,38 @@ def dp_objective(mll, output, y_local, batch_global, world, negate=False):
 class DataParallel:
     """Wraps a FlatBucket: `allreduce_grads()` sums the bucket over the process group."""
 
-    def __init__(self, bucket, group=None):
+    def __init__(self, bucket, group=None, force=False):
+        """force=True: issue the collectives even in a one-rank group (rehearsal of the N>1 call sequence on one GPU)."""
         self.bucket, self.group = bucket, group
+        self._pending = []
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.active = self.world > 1 or (force and dist.is_initialized())
 
     def broadcast_params(self, src=0):
-        if self.world > 1:
+        if self.active:
             dist.broadcast(self.bucket.flat_p, src=src, group=self.group)
+
+    def allreduce_stage(self, stage, gather=True):
+        """Staged backward (nsgp/stages.py): start the sum-all-reduce of the gradients that backward stage `stage`
+        completed -- one contiguous range of the bucket -- without waiting for it; `wait_stages()` joins them all.  The
+        collective runs on the process group's own stream, so kernels launched afterwards (the next stage of the
+        backward) overlap with it.  Same SUM over the same values as `allreduce_grads`, in up to `num_stages` pieces."""
+        if gather:
+            self.bucket.gather_grads(stage)
+        seg = self.bucket.segments.get(stage)
+        if self.active and seg is not None and seg[1] > seg[0]:
+            self._pending.append(dist.all_reduce(self.bucket.flat_g[seg[0]:seg[1]], op=dist.ReduceOp.SUM,
+                                                 group=self.group, async_op=True))
+
+    def wait_stages(self):
+        for work in self._pending:
+            work.wait()                       # device tensors: the current stream waits, the host does not block
+        self._pending = []
 
     def allreduce_grads(self, async_op=False, gather=True):
         if gather:
             self.bucket.gather_grads()
-        if self.world > 1:
+        if self.active:
             return dist.all_reduce(self.bucket.flat_g, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         return None

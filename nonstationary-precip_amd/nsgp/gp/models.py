@@ -8,7 +8,7 @@ from . import settings
 from .distributions import MultivariateNormal, MultitaskMultivariateNormal
 from .lazy import delazify
 from .likelihoods import GaussianLikelihood
-from .module import Module, prefill_softplus_transforms, transform_cache
+from .module import Module, cut_cached_transforms, prefill_softplus_transforms, transform_cache
 
 
 class GP(Module):
@@ -119,6 +119,9 @@ class DeepGPLayer(ApproximateGP):
                 eps = prov((S, n, b), mean_tsn.dtype, mean_tsn.device)
             inputs = ops.DgpSampleFn.apply(mean_tsn, var_tsn, eps)           # (S, n, b)
             deterministic_inputs = False
+            plan = settings.backward_stages.value()
+            if plan is not None:                         # staged backward: this layer and what follows form a stage
+                inputs, = plan.cut([inputs])
         if settings.debug.on():
             if not torch.is_tensor(inputs):
                 raise ValueError('`inputs` should either be a MultitaskMultivariateNormal or a Tensor, got '
@@ -188,9 +191,14 @@ class DeepGP(GP):
         strategies = [s for s in self.variational_strategy.sub_variational_strategies
                       if hasattr(s, 'whiten_group')]
         shared = False
+        plan = settings.backward_stages.value()
+        if plan is not None:
+            plan.begin()
         with transform_cache():
             if args and torch.is_tensor(args[0]) and args[0].is_cuda:
-                prefill_softplus_transforms(self)         # all raw hyper-parameters in one softplus launch
+                keys = prefill_softplus_transforms(self)  # all raw hyper-parameters in one softplus launch
+                if plan is not None:
+                    cut_cached_transforms(keys, plan)
             if len(strategies) > 1 and len({s.inducing_points.shape[-2] for s in strategies}) == 1 \
                     and args and torch.is_tensor(args[0]) and args[0].is_cuda:
                 for s in strategies:
@@ -199,6 +207,10 @@ class DeepGP(GP):
                 Ws, _info, passed, W64s = whiten(groups, settings.variational_cholesky_jitter.value(args[0].dtype),
                                                  settings.chol_bwd_f64.on(), passthrough=True, out_dtype=args[0].dtype,
                                                  with_f64=True)
+                if plan is not None:                     # staged backward: the whitening chain's adjoint is its own stage
+                    flat = plan.cut(list(Ws) + [t for zlo in passed for t in zlo])
+                    Ws, passed = flat[:len(Ws)], [tuple(flat[len(Ws) + 3 * i:len(Ws) + 3 * i + 3])
+                                                  for i in range(len(passed))]
                 for s, W, zlo, Wd in zip(strategies, Ws, passed, W64s):
                     s._W64_shared = W
                     s._W64f_shared = Wd                      # float64 companion (forward projection accumulates in it)

@@ -72,7 +72,7 @@ def prefill_softplus_transforms(root):
     models/dgps.py has five such parameters: two lengthscales, two output scales, the noise.)"""
     import math
     if not _transform_cache:
-        return
+        return []
     cache = _transform_cache[-1]
     todo, seen = [], set()
     for mod in root.modules():
@@ -90,7 +90,7 @@ def prefill_softplus_transforms(root):
             seen.add(id(p))
             todo.append((key, p, float(c.lower_bound)))
     if len(todo) < 2 or len({(t[1].dtype, t[1].device) for t in todo}) != 1:
-        return
+        return []
     sp = torch.nn.functional.softplus(torch.cat([p.reshape(-1) for _, p, _ in todo]))
     if any(lb != 0.0 for _, _, lb in todo):
         k = (tuple((id(p), p.numel(), lb) for _, p, lb in todo), sp.dtype, sp.device)
@@ -101,6 +101,16 @@ def prefill_softplus_transforms(root):
         sp = sp + vec
     for (key, _, _), val in zip(todo, _SplitPackedFn.apply(sp, *[tuple(p.shape) for _, p, _ in todo])):
         cache[key] = val
+    return [key for key, _, _ in todo]
+
+
+def cut_cached_transforms(keys, plan):
+    """Staged backward (nsgp/stages.py): the cached softplus values under `keys` become leaves of `plan`."""
+    if not keys or not _transform_cache:
+        return
+    cache = _transform_cache[-1]
+    for key, leaf in zip(keys, plan.cut([cache[k] for k in keys])):
+        cache[key] = leaf
 
 
 class Module(nn.Module):

@@ -150,3 +150,10 @@ class check_variational_cholesky(_feature_flag):
     factorisation's LAPACK-style `info` after every whitening chain (one host sync per model call) and raise
     NotPSDError naming the failing GP and leading minor; meant for debugging, not for graph-captured training."""
     _state = False
+
+
+class backward_stages(_value_context):
+    """An nsgp.stages.BackwardStages plan: while set, DeepGP / DeepGPLayer cut the autograd graph between the parts of
+    the model so that the backward pass can be run part by part (gradient exchange overlapped with it, nsgp/dist.py).
+    None (default): one ordinary backward."""
+    _global_value = None

@@ -25,3 +25,41 @@ class GraphedCallable:
     def __call__(self):
         self.graph.replay()
         return self.out
+
+
+class GraphedSequence:
+    """fns[0], between[0], fns[1], between[1], ...: every `fn` captured as its own hipGraph, the `between` callables
+    (collectives of the data-parallel step) stay eager calls between the replays.  The graphs share one memory pool --
+    tensors made by one part (autograd graph, gradients of the cut leaves of a staged backward) are consumed by the
+    next -- and are always replayed in capture order."""
+
+    def __init__(self, fns, between, warmup=3):
+        assert len(between) == len(fns)
+        self.fns, self.between = list(fns), list(between)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                for fn, bt in zip(self.fns, self.between):
+                    fn()
+                    if bt is not None:
+                        bt()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        pool = torch.cuda.graph_pool_handle()
+        self.graphs, self.outs = [], []
+        for fn, bt in zip(self.fns, self.between):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool, capture_error_mode='thread_local'):
+                out = fn()
+            self.graphs.append(g)
+            self.outs.append(out)
+            if bt is not None:
+                bt()
+
+    def __call__(self):
+        for g, bt in zip(self.graphs, self.between):
+            g.replay()
+            if bt is not None:
+                bt()
+        return self.outs

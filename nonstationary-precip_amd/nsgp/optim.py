@@ -19,7 +19,7 @@ class FlatBucket:
     its own buffers (no launch, no memset), and `gather_grads()` packs them into the bucket with one
     multi-tensor copy -- fewer launches per step; FusedAdam and DataParallel call it themselves."""
 
-    def __init__(self, params, grads_as_views=True):
+    def __init__(self, params, grads_as_views=True, stage_of=None):
         seen, plist = set(), []
         for p in params:
             if p.requires_grad and id(p) not in seen:
@@ -27,26 +27,50 @@ class FlatBucket:
                 plist.append(p)
         if not plist:
             raise ValueError('FlatBucket: no trainable parameters')
+        # `stage_of` ({id(p): k}, nsgp.stages.BackwardStages.final_stage_of): lay the parameters out by the backward
+        # stage that completes their gradient, so every stage's gradients are ONE contiguous range of the bucket
+        # (`segments`) and can be exchanged as soon as that stage has run.
+        if stage_of is not None:
+            plist.sort(key=lambda p: stage_of.get(id(p), 0))          # stable: model order within a stage
         dev, dt = plist[0].device, plist[0].dtype
         for p in plist:
             if p.device != dev or p.dtype != dt:
                 raise ValueError('FlatBucket: all parameters must share device and dtype')
         self.params = plist
         self.grads_as_views = grads_as_views
-        self.numel = sum(p.numel() for p in plist)
-        self.flat_p = torch.empty(self.numel, dtype=dt, device=dev)
+        # every parameter starts on a 256-byte boundary of the bucket: the GEMM / kernel-build loaders take their 16-byte
+        # path only for aligned operands (an odd-sized neighbour, e.g. a 1-element mean constant in front of a 1024 x 1024
+        # Cholesky factor, would otherwise push every later parameter onto the element-wise edge path: 2.5x slower
+        # projections).  The padding elements stay zero (zero gradient -> Adam leaves them at zero).
+        ALIGN = 256 // torch.empty((), dtype=dt).element_size()
+        starts, off = [], 0
+        for p in plist:
+            starts.append(off)
+            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.numel = off                                            # bucket length, padding included
+        self.num_param_elements = sum(p.numel() for p in plist)
+        self.flat_p = torch.zeros(self.numel, dtype=dt, device=dev)
         self.flat_g = torch.zeros(self.numel, dtype=dt, device=dev)
-        off = 0
         self.offsets = []
         with torch.no_grad():
-            for p in plist:
+            for p, off in zip(plist, starts):
                 n = p.numel()
                 self.flat_p[off:off + n].copy_(p.reshape(-1))
                 p.data = self.flat_p[off:off + n].view(p.shape)
                 p.grad = self.flat_g[off:off + n].view(p.shape) if grads_as_views else None
                 self.offsets.append((off, n))
-                off += n
         self.grad_views = [self.flat_g[off:off + n].view(p.shape) for p, (off, n) in zip(plist, self.offsets)]
+        self.stage_index = [0 if stage_of is None else int(stage_of.get(id(p), 0)) for p in plist]
+        self.segments = {}                                             # stage -> (first element, one past the last)
+        for k, (off, n) in zip(self.stage_index, self.offsets):
+            end = (off + n + ALIGN - 1) // ALIGN * ALIGN                # the padding travels with its parameter
+            a, b = self.segments.get(k, (off, off))
+            self.segments[k] = (min(a, off), max(b, end))
+
+    def unpadded(self, flat):
+        """The parameters' elements of a bucket-shaped buffer (flat_p, flat_g, an Adam moment) without the alignment
+        padding, concatenated in bucket order."""
+        return torch.cat([flat[off:off + n] for off, n in self.offsets])
 
     def zero_grad(self):
         if not self.grads_as_views:
@@ -67,13 +91,16 @@ class FlatBucket:
                 raise RuntimeError('FlatBucket: a parameter was moved out of the flat buffer (model.to()/.double()/'
                                    '.cuda() after the optimiser was built?); rebuild the FlatBucket / FusedAdam')
 
-    def gather_grads(self):
-        """Pack the parameters' .grad tensors into the flat gradient buffer (no-op for view gradients)."""
+    def gather_grads(self, stage=None):
+        """Pack the parameters' .grad tensors into the flat gradient buffer (no-op for view gradients); `stage`: only
+        the parameters of that backward stage (their range of the bucket is `segments[stage]`)."""
         self.check_homed()
         if self.grads_as_views:
             return
         dst, src, missing = [], [], []
-        for p, v in zip(self.params, self.grad_views):
+        for p, v, k in zip(self.params, self.grad_views, self.stage_index):
+            if stage is not None and k != stage:
+                continue
             if p.grad is None:
                 missing.append(v)
             elif p.grad.data_ptr() != v.data_ptr():
@@ -89,8 +116,9 @@ class FusedAdam:
     """torch.optim.Adam semantics (no weight decay, no amsgrad) over a FlatBucket, one kernel per step.
     `capturable=True` keeps the step count on the device so the update can live in a hipGraph."""
 
-    def __init__(self, params, lr=0.01, betas=(0.9, 0.999), eps=1e-8, capturable=False, grads_as_views=True):
-        self.bucket = params if isinstance(params, FlatBucket) else FlatBucket(list(params), grads_as_views)
+    def __init__(self, params, lr=0.01, betas=(0.9, 0.999), eps=1e-8, capturable=False, grads_as_views=True,
+                 stage_of=None):
+        self.bucket = params if isinstance(params, FlatBucket) else FlatBucket(list(params), grads_as_views, stage_of)
         if self.bucket.flat_p.dtype != torch.float32:
             raise ValueError('FusedAdam: float32 parameters expected')
         self.lr, self.betas, self.eps = lr, betas, eps
@@ -110,14 +138,18 @@ class FusedAdam:
         return {'step': int(self.steps), 'exp_avg': self.exp_avg.detach().clone(),
                 'exp_avg_sq': self.exp_avg_sq.detach().clone(), 'lr': float(self.lr),
                 'betas': [float(self.betas[0]), float(self.betas[1])], 'eps': float(self.eps),
-                'numel': int(self.bucket.numel)}
+                'numel': int(self.bucket.num_param_elements),
+                'layout': [[int(off), int(n)] for off, n in self.bucket.offsets]}
 
     def load_state_dict(self, state):
         """In-place restore: the moment buffers and the device step counter keep their addresses, so a hipGraph
         captured around step() stays valid."""
-        if int(state['numel']) != self.bucket.numel:
+        if int(state['numel']) != self.bucket.num_param_elements:
             raise ValueError(f"FusedAdam.load_state_dict: {state['numel']} parameters in the checkpoint, "
-                             f'{self.bucket.numel} in the bucket')
+                             f'{self.bucket.num_param_elements} in the bucket')
+        if [list(map(int, x)) for x in state.get('layout', [])] != [[int(off), int(n)] for off, n in self.bucket.offsets]:
+            raise ValueError('FusedAdam.load_state_dict: the checkpoint was written with a different bucket layout '
+                             '(parameter order / staged-backward grouping)')
         with torch.no_grad():
             self.exp_avg.copy_(state['exp_avg'])
             self.exp_avg_sq.copy_(state['exp_avg_sq'])

@@ -73,7 +73,7 @@ def _worker(rank, world, port, out_dir):
     dp.allreduce_grads()
     dist.all_reduce(local)
     if rank == 0:
-        np.savez(os.path.join(out_dir, 'dp.npz'), obj=local.numpy(), grad=bucket.flat_g.numpy())
+        np.savez(os.path.join(out_dir, 'dp.npz'), obj=local.numpy(), grad=bucket.unpadded(bucket.flat_g).numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -95,11 +95,14 @@ def test_flat_bucket_views_and_zero_grad():
           torch.nn.Parameter(torch.randn(2, 2), requires_grad=False)]
     before = [p.detach().clone() for p in ps]
     b = FlatBucket(ps)
-    assert b.numel == 17
+    assert b.num_param_elements == 17 and b.numel == 128       # every parameter starts on a 256-byte boundary
+    assert all(off % 64 == 0 for off, _ in b.offsets)
     assert torch.equal(ps[0], before[0]) and torch.equal(ps[1], before[1])
     (ps[0].sum() * 2 + (ps[1] ** 2).sum()).backward()
     assert torch.allclose(b.flat_g[:12], torch.full((12,), 2.0))
-    assert torch.allclose(b.flat_g[12:], 2 * before[1])
+    assert torch.allclose(b.flat_g[64:69], 2 * before[1])
+    assert torch.allclose(b.unpadded(b.flat_g), torch.cat([torch.full((12,), 2.0), 2 * before[1]]))
+    assert float(b.flat_g[12:64].abs().sum()) == 0.0 and float(b.flat_g[69:].abs().sum()) == 0.0      # padding stays zero
     b.zero_grad()
     assert float(b.flat_g.abs().sum()) == 0.0 and ps[0].grad.data_ptr() == b.flat_g.data_ptr()
     with torch.no_grad():

@@ -20,7 +20,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(rank, world, port, out_path, steps):
+def _run(rank, world, port, out_path, steps, staged=False):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, 'nonstationary-precip_amd')):
@@ -42,27 +42,58 @@ def _run(rank, world, port, out_path, steps):
     g = torch.Generator().manual_seed(5)
     x = torch.randn(B, D, generator=g).cuda()
     y = torch.randn(B, generator=g).cuda()
-    opt = FusedAdam(model.parameters(), lr=0.01, capturable=True, grads_as_views=False)
+    lo, hi = shard_bounds(B, world, rank)
+    model.train()
+    plan, stage_of = None, None
+    if staged:
+        # staged backward (nsgp/stages.py): per-stage asynchronous all-reduces of contiguous bucket ranges
+        from nsgp.stages import BackwardStages
+        plan = BackwardStages()
+        with settings.num_likelihood_samples(S), settings.eps_provider(PhiloxEps(173, row0=lo)), \
+                settings.backward_stages(plan):
+            probe = -dp_objective(mll, model(x[lo:hi]), y[lo:hi], B, world)
+        stage_of = plan.final_stage_of(probe, [p for p in model.parameters() if p.requires_grad])
+        assert plan.num_stages == 4                       # loss + last layer | hidden layer | whitening chain | softplus
+    opt = FusedAdam(model.parameters(), lr=0.01, capturable=True, grads_as_views=False, stage_of=stage_of)
+    if staged:
+        names = {id(p): n for n, p in model.named_parameters()}
+        by_stage = {}
+        for p, k in zip(opt.bucket.params, opt.bucket.stage_index):
+            by_stage.setdefault(k, []).append(names[id(p)])
+        assert any('last_layer' in n and 'chol_variational_covar' in n for n in by_stage[0]), by_stage
+        assert all('last_layer' not in n or 'variational' not in n for n in by_stage[1]), by_stage
+        assert any('chol_variational_covar' in n for n in by_stage[1]), by_stage
+        assert all('inducing_points' in n for n in by_stage[2]), by_stage
+        assert all('raw_' in n for n in by_stage[3]), by_stage
+        segs = sorted(opt.bucket.segments.values())
+        assert segs[0][0] == 0 and segs[-1][1] == opt.bucket.numel
+        assert all(a[1] == b[0] for a, b in zip(segs, segs[1:]))           # contiguous, disjoint, complete
     dp = DataParallel(opt.bucket)
     dp.broadcast_params()
-    lo, hi = shard_bounds(B, world, rank)
     eps = PhiloxEps(173, row0=lo, step_dev=opt.step_dev)
-    model.train()
     losses = []
     with settings.num_likelihood_samples(S), settings.eps_provider(eps):
         for _ in range(steps):
             eps.start_step(0, row0=lo)
             opt.zero_grad()
-            loss = -dp_objective(mll, model(x[lo:hi]), y[lo:hi], B, world)
-            loss.backward()
-            dp.allreduce_grads()
+            if staged:
+                with settings.backward_stages(plan):
+                    loss = -dp_objective(mll, model(x[lo:hi]), y[lo:hi], B, world)
+                plan.backward(loss, after_stage=dp.allreduce_stage)
+                dp.wait_stages()
+            else:
+                loss = -dp_objective(mll, model(x[lo:hi]), y[lo:hi], B, world)
+                loss.backward()
+                dp.allreduce_grads()
             opt.step(gather=False)
             t = loss.detach().clone().reshape(1)
             if world > 1:
                 dist.all_reduce(t)
             losses.append(float(t))
     if rank == 0:
-        torch.save({'p': opt.bucket.flat_p.detach().cpu(), 'losses': torch.tensor(losses)}, out_path)
+        # parameters by NAME: the staged run lays the bucket out in a different order
+        torch.save({'p': torch.cat([p.detach().reshape(-1).cpu() for _, p in sorted(model.named_parameters())]),
+                    'losses': torch.tensor(losses)}, out_path)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -84,6 +115,26 @@ def test_two_rank_data_parallel_training_equals_single_process(tmp_path):
     assert a['losses'][-1] < a['losses'][0]
     assert float((a['p'] - b['p']).abs().max()) < 2e-3
     assert float((a['p'] - b['p']).abs().mean()) < 2e-5
+
+
+def test_staged_backward_with_overlapped_exchange_equals_single_process(tmp_path):
+    """The staged backward (graph cut between the layers, the whitening chain and the packed softplus; every stage's
+    gradients exchanged asynchronously as one contiguous range of the bucket) trains to the same parameters as the plain
+    single-process step: one rank staged == one rank plain (no node runs twice, nothing is dropped), and two staged ranks
+    == one rank."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    steps = 4
+    one, st1, st2 = str(tmp_path / 'one.pt'), str(tmp_path / 'st1.pt'), str(tmp_path / 'st2.pt')
+    mp.spawn(_run, args=(1, 0, one, steps), nprocs=1, join=True)
+    mp.spawn(_run, args=(1, 0, st1, steps, True), nprocs=1, join=True)
+    mp.spawn(_run, args=(2, _free_port(), st2, steps, True), nprocs=2, join=True)
+    a = torch.load(one, weights_only=True)
+    for path in (st1, st2):
+        b = torch.load(path, weights_only=True)
+        assert torch.allclose(a['losses'], b['losses'], rtol=2e-5, atol=1e-6), (a['losses'], b['losses'])
+        assert float((a['p'] - b['p']).abs().max()) < 2e-3
+        assert float((a['p'] - b['p']).abs().mean()) < 2e-5
 
 
 def _bench_line(nproc, extra, port):
@@ -125,6 +176,15 @@ def test_bench_two_rank_control_flow_matches_one_rank():
         assert r['rows_per_sec'] == pytest.approx(4096 * r['iterations_per_sec'], rel=1e-3)
         assert 'roofline' in r and r['roofline']['bound'] == 'mfma'
     assert two['final_loss'] == pytest.approx(one['final_loss'], rel=2e-4)
+    # N > 1 runs the staged backward by default: three exchange groups (last layer | hidden layer | the rest)
+    ex = two['gradient_exchange']
+    assert ex['exchange_groups'] == 3 and ex['backward_stages'] == 4
+    assert sum(ex['group_bytes']) > 12_000_000                              # the whole 12.6 MB bucket
+    assert ex['group_bytes'][0] > 4_000_000 and ex['group_bytes'][1] > 8_000_000 and ex['group_bytes'][2] < 100_000
+    flat = _bench_line(2, ['--no-overlap'], _free_port())                   # one all-reduce after the backward pass
+    assert flat['final_loss'] == pytest.approx(one['final_loss'], rel=2e-4)
+    st = _bench_line(1, ['--staged'], 0)                                    # the staging itself, priced at N = 1
+    assert st['final_loss'] == pytest.approx(one['final_loss'], rel=2e-4)
     weak = _bench_line(2, ['--scaling', 'weak'], _free_port())
     assert weak['scaling'] == 'weak' and weak['config']['global_batch'] == 8192
     assert weak['value'] == pytest.approx(2 * weak['iterations_per_sec'], rel=1e-3)

@@ -81,7 +81,7 @@ def test_fused_adam_state_dict_round_trip_and_bucket_homing():
     opt = FusedAdam(lin.parameters(), lr=0.02, capturable=False)
     opt.exp_avg.normal_(); opt.exp_avg_sq.uniform_(); opt.steps = 17
     sd = opt.state_dict()
-    assert set(sd) == {'step', 'exp_avg', 'exp_avg_sq', 'lr', 'betas', 'eps', 'numel'}
+    assert set(sd) == {'step', 'exp_avg', 'exp_avg_sq', 'lr', 'betas', 'eps', 'numel', 'layout'}
     buf = __import__('io').BytesIO()
     torch.save(sd, buf); buf.seek(0)
     sd2 = torch.load(buf, weights_only=True)                       # loads without unpickling arbitrary objects

@@ -41,7 +41,7 @@ def main():
             'aten::matmul', 'aten::exp', 'aten::to', 'aten::_to_copy', 'aten::clone', 'aten::mean', 'aten::sigmoid')
     rows = {}
     for ev in prof.events():
-        if ev.name in want and ev.self_device_time_total > 0:
+        if (ev.name in want or ev.name.startswith('aten::_foreach') or os.environ.get('ALL_OPS')) and ev.name.startswith('aten::') and ev.self_device_time_total > 0:
             src = [s for s in ev.stack if 'nonstationary-precip_amd' in s or 'bench.py' in s]
             where = src[0].split('nonstationary-precip_amd/')[-1] if src else ('autograd engine' if not ev.stack else ev.stack[0][-60:])
             key = (ev.name, str([tuple(x) for x in ev.input_shapes if x]), where)
