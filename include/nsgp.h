@@ -127,6 +127,8 @@ int nsgp_ps2d_build_bwd_f64(const double* x1, const double* x2, const double* si
 #define NSGP_GEMM_C_LOWER  16   /* only the lower triangle (n <= m) of C is computed/stored; the
                                    strict upper triangle is written as zero when beta == 0 */
 #define NSGP_GEMM_NO_SPLITK 32  /* never split the inner dimension (no workspace needed) */
+#define NSGP_GEMM_C_NOFILL  64  /* with C_LOWER: leave the strict upper triangle of C untouched (the consumer reads C
+                                   through a LOWER operand flag, which never loads it) -- no memset nodes */
 size_t nsgp_gemm_workspace(int64_t M, int64_t N, int64_t K, int64_t nb1, int64_t nb2, int elem_size, int flags);
 int nsgp_gemm_f32(int64_t M, int64_t N, int64_t K, float alpha,
                   const float* A, int64_t sam, int64_t sak, int64_t sa1, int64_t sa2,
@@ -380,6 +382,10 @@ int nsgp_kl_whitened_bwd_f64(const double* m, const double* Lq, int64_t batch, i
 /* ------------------------------------------------------------------------------------------
  * Small helpers on the same stream
  * ------------------------------------------------------------------------------------------ */
+/* P(i,i) *= factor for a batch of n x n matrices, in place (Phi of the Cholesky backward: tril with halved diagonal,
+ * the strict upper triangle being masked by the GEMM that consumes P as a LOWER operand) */
+int nsgp_scale_diag_f32(float* P, int64_t n, int64_t ld, int64_t sP, int64_t batch, float factor, void* stream);
+int nsgp_scale_diag_f64(double* P, int64_t n, int64_t ld, int64_t sP, int64_t batch, double factor, void* stream);
 /* out = tril(P) with halved diagonal, symmetrised: S = Phi(P) + Phi(P)^T   (Cholesky backward) */
 int nsgp_chol_bwd_phi_sym_f32(const float* P, float* S, int64_t n, int64_t ld, int64_t sP, int64_t batch, void* stream);
 int nsgp_chol_bwd_phi_sym_f64(const double* P, double* S, int64_t n, int64_t ld, int64_t sP, int64_t batch, void* stream);

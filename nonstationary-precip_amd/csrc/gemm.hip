@@ -214,6 +214,9 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && sizeof(T) == 4) ? 3 
         // no faster than the full one, CUs ~58 % busy).  Rows 0..T-1 form a triangle, the rest are full.
         const int TT = tiles_m < tiles_n ? tiles_m : tiles_n;
         const int tri = TT * (TT + 1) / 2;
+        // triangular operands on top (Cholesky adjoint: tril(Wbar W^T), Phi W): the K range grows with the row, issue the
+        // large rows first (the mirror flips below would leave the lower triangle)
+        if (g.flags & (NSGP_GEMM_A_LOWER | NSGP_GEMM_B_UPPER)) tid_lin = (int)gridDim.x - 1 - tid_lin;
         if (tid_lin < tri) {
             int r = (int)((sqrtf(8.0f * (float)tid_lin + 1.0f) - 1.0f) * 0.5f);
             while (r * (r + 1) / 2 > tid_lin) --r;
@@ -244,8 +247,10 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && sizeof(T) == 4) ? 3 
         // (j - row) mod tiles_n: spreads a triangular B operand's heavy columns over the XCDs (id % 8)
         bm = brow; bn = (tid_lin % tiles_n + tiles_n - brow % tiles_n) % tiles_n;
     }
-    if (g.flags & NSGP_GEMM_A_LOWER) bm = tiles_m - 1 - bm;            // large m = long K range
-    if (g.flags & NSGP_GEMM_B_UPPER) bn = tiles_n - 1 - bn;            // large n = long K range
+    if (!(g.flags & NSGP_GEMM_C_LOWER)) {
+        if (g.flags & NSGP_GEMM_A_LOWER) bm = tiles_m - 1 - bm;        // large m = long K range
+        if (g.flags & NSGP_GEMM_B_UPPER) bn = tiles_n - 1 - bn;        // large n = long K range
+    }
     const int ksp = (int)g.ksplit, nb2i = (int)g.nb2;
     const int64_t slice = zz % ksp, bb = zz / ksp;
     const int64_t b1 = (int)bb / nb2i, b2 = (int)bb % nb2i;
@@ -820,7 +825,7 @@ int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam,
     g.tiles_n = cdiv64(N, p.narrow ? 64 : bmn);
     if (g.tiles_m * g.tiles_n > 2147483647LL || nb * g.ksplit > 65535) return -24;
     const int64_t ngrid = (flags & NSGP_GEMM_C_LOWER) ? active_tiles(M, N, bmn, flags) : g.tiles_m * g.tiles_n;
-    if ((flags & NSGP_GEMM_C_LOWER) && g.ksplit == 1 && beta == T(0)) {
+    if ((flags & NSGP_GEMM_C_LOWER) && !(flags & NSGP_GEMM_C_NOFILL) && g.ksplit == 1 && beta == T(0)) {
         // the strictly-upper tiles are not launched: keep the "strict upper triangle is zero" contract
         // (the split-K reduce kernel writes those zeros itself)
         for (int64_t i1 = 0; i1 < nb1; ++i1)

@@ -17,6 +17,14 @@ __global__ void phi_sym_kernel(const T* __restrict__ P, T* __restrict__ S, int64
     S[b * sP + i * ld + j] = (i >= j) ? Pb[i * ld + j] : Pb[j * ld + i];
 }
 
+template <typename T>
+__global__ void scale_diag_kernel(T* __restrict__ P, int64_t n, int64_t ld, int64_t sP, int64_t batch, T factor) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= batch * n) return;
+    const int64_t b = idx / n, i = idx % n;
+    P[b * sP + i * ld + i] *= factor;
+}
+
 template <typename TS, typename TD>
 __global__ void cast_kernel(const TS* __restrict__ src, int64_t lds, TD* __restrict__ dst, int64_t ldd, int64_t rows,
                             int64_t cols) {
@@ -128,6 +136,15 @@ int phi_impl(const T* P, T* S, int64_t n, int64_t ld, int64_t sP, int64_t batch,
     return nsgp_launch_status();
 }
 
+template <typename T>
+int scale_diag_impl(T* P, int64_t n, int64_t ld, int64_t sP, int64_t batch, T factor, void* stream) {
+    if (!P) return -1; if (n < 0) return -2; if (ld < n) return -3; if (batch < 0) return -5;
+    if (batch * n == 0) return 0;
+    hipLaunchKernelGGL((scale_diag_kernel<T>), dim3((unsigned)cdiv64(batch * n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       P, n, ld, sP, batch, factor);
+    return nsgp_launch_status();
+}
+
 template <typename TS, typename TD>
 int cast_impl(const TS* src, int64_t lds, TD* dst, int64_t ldd, int64_t rows, int64_t cols, void* stream) {
     if (!src) return -1; if (lds < cols) return -2; if (!dst) return -3; if (ldd < cols) return -4;
@@ -165,6 +182,12 @@ int nsgp_chol_bwd_phi_sym_f32(const float* P, float* S, int64_t n, int64_t ld, i
 int nsgp_chol_bwd_phi_sym_f64(const double* P, double* S, int64_t n, int64_t ld, int64_t sP, int64_t batch,
                               void* stream) {
     return phi_impl<double>(P, S, n, ld, sP, batch, stream);
+}
+int nsgp_scale_diag_f32(float* P, int64_t n, int64_t ld, int64_t sP, int64_t batch, float factor, void* stream) {
+    return scale_diag_impl<float>(P, n, ld, sP, batch, factor, stream);
+}
+int nsgp_scale_diag_f64(double* P, int64_t n, int64_t ld, int64_t sP, int64_t batch, double factor, void* stream) {
+    return scale_diag_impl<double>(P, n, ld, sP, batch, factor, stream);
 }
 int nsgp_cast_f64_to_f32(const double* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int64_t cols,
                          void* stream) {

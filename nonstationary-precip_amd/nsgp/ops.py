@@ -15,7 +15,7 @@ import torch
 from . import _lib
 from ._lib import BackendError
 
-GEMM_A_LOWER, GEMM_A_UPPER, GEMM_B_LOWER, GEMM_B_UPPER, GEMM_C_LOWER, GEMM_NO_SPLITK = 1, 2, 4, 8, 16, 32
+GEMM_A_LOWER, GEMM_A_UPPER, GEMM_B_LOWER, GEMM_B_UPPER, GEMM_C_LOWER, GEMM_NO_SPLITK, GEMM_C_NOFILL = 1, 2, 4, 8, 16, 32, 64
 
 
 # --------------------------------------------------------------------------------------------
@@ -400,6 +400,17 @@ def chol_bwd_phi_sym(P):
     S = torch.empty_like(P)
     _lib.call(f'nsgp_chol_bwd_phi_sym_{_sfx(ref)}', _p(P), _p(S), n, n, n * n, batch, _stream())
     return S
+
+
+def scale_diag_(P, factor):
+    """P[..., i, i] *= factor in place (batch of square matrices)."""
+    ref = _chk(P)
+    if not P.is_contiguous():
+        raise BackendError('scale_diag_: contiguous matrices expected')
+    n = P.shape[-1]
+    batch = P.shape[0] if P.dim() == 3 else 1
+    _lib.call(f'nsgp_scale_diag_{_sfx(ref)}', _p(P), n, n, n * n, batch, float(factor), _stream())
+    return P
 
 
 def cast(t, dtype):

@@ -19,7 +19,7 @@ folded into a GEMM epilogue and an operand loader) + one batched M^3 Cholesky ad
 import torch
 
 from . import ops
-from .ops import GEMM_A_LOWER, GEMM_A_UPPER, GEMM_B_LOWER, GEMM_B_UPPER, GEMM_C_LOWER
+from .ops import GEMM_A_LOWER, GEMM_A_UPPER, GEMM_B_LOWER, GEMM_B_UPPER, GEMM_C_LOWER, GEMM_C_NOFILL
 
 VAR_JITTER = 1e-4          # data_data_covar.add_jitter(1e-4) in VariationalStrategy.forward
 
@@ -97,10 +97,15 @@ class WhitenFn(torch.autograd.Function):
             Wb, Wc = Wbar.contiguous(), W64
         else:
             Wb, Wc = ops.cast(Wbar.contiguous(), torch.float32), ops.cast(W64, torch.float32)
-        Bm = ops.gemm(Wb, Wc, tb=True, flags=GEMM_A_LOWER | GEMM_B_UPPER)
-        S = ops.chol_bwd_phi_sym(Bm)
-        T = ops.gemm(S, Wc, flags=GEMM_B_LOWER)
-        Kbar = ops.gemm(Wc, T, ta=True, alpha=-0.5, flags=GEMM_A_UPPER)
+        # Kbar = -1/2 W^T (Phi + Phi^T) W with Phi = tril(Wbar W^T), diagonal halved.  The kernel backward below sums the
+        # row and the column side of its input (sym=True), i.e. it sees Kbar + Kbar^T only, so G = -W^T Phi W stands in for
+        # Kbar (G + G^T = 2 Kbar): every product keeps its triangular structure -- lower triangle of a lower x upper
+        # product, lower x lower (lower result), upper x lower -- 2/3 of a dense M^3 product in total instead of 4/3.
+        # The strict upper triangles of Phi and Phi W are never written and never read (LOWER operand flags mask them).
+        Phi = ops.gemm(Wb, Wc, tb=True, flags=GEMM_A_LOWER | GEMM_B_UPPER | GEMM_C_LOWER | GEMM_C_NOFILL)
+        ops.scale_diag_(Phi, 0.5)
+        T = ops.gemm(Phi, Wc, flags=GEMM_A_LOWER | GEMM_B_LOWER | GEMM_C_LOWER | GEMM_C_NOFILL)
+        Kbar = ops.gemm(Wc, T, ta=True, alpha=-1.0, flags=GEMM_A_UPPER | GEMM_B_LOWER)
         grads, off = [None, None], 0
         for gi, b in enumerate(ctx.sizes):
             Zd, lsd, osd = flat[3 * gi:3 * gi + 3]

@@ -266,6 +266,36 @@ def test_gemm_triangular_flags_mask_the_other_triangle(ops, dt, n):
     assert torch.allclose(got, torch.tril(X.double() @ X.double().T), **tol)
 
 
+@pytest.mark.parametrize('dt', [F32, F64])
+@pytest.mark.parametrize('n,batch', [(200, 1), (512, 3), (1024, 2)])
+def test_gemm_combined_triangular_flags_of_the_cholesky_adjoint(ops, dt, n, batch):
+    """The three products of WhitenFn.backward keep all their triangular structure: lower triangle of (lower x upper),
+    lower x lower (a lower result), upper x lower.  Garbage (incl. NaN for the never-written triangle) sits in every
+    triangle the flags declare zero; with C_NOFILL the strict upper triangle of an output is unspecified."""
+    g = _g(40 + n)
+    Wb = torch.randn(batch, n, n, generator=g, dtype=dt)
+    W = torch.randn(batch, n, n, generator=g, dtype=dt) / n ** 0.5
+    junk = torch.triu(torch.full((n, n), float('nan'), dtype=dt), 1)
+    Wb_in, W_in = (torch.tril(Wb) + junk).cuda(), (torch.tril(W) + junk).cuda()
+    Wbl, Wl = torch.tril(Wb).double(), torch.tril(W).double()
+    tol = dict(rtol=1e-11, atol=1e-10) if dt == F64 else dict(rtol=2e-4, atol=2e-3)
+    fl = ops.GEMM_C_LOWER | ops.GEMM_C_NOFILL
+    Phi = torch.full((batch, n, n), 7.0, dtype=dt, device='cuda')
+    ops.gemm(Wb_in, W_in, tb=True, flags=ops.GEMM_A_LOWER | ops.GEMM_B_UPPER | fl, out=Phi)
+    ref = Wbl @ Wl.transpose(-1, -2)
+    assert torch.allclose(torch.tril(Phi.cpu().double()), torch.tril(ref), **tol)
+    ops.scale_diag_(Phi, 0.5)
+    Phi_ref = torch.tril(ref) - 0.5 * torch.diag_embed(torch.diagonal(ref, dim1=-2, dim2=-1))
+    assert torch.allclose(torch.tril(Phi.cpu().double()), Phi_ref, **tol)
+    Phi_in = torch.tril(Phi) + junk.cuda()
+    T = ops.gemm(Phi_in, W_in, flags=ops.GEMM_A_LOWER | ops.GEMM_B_LOWER | fl)
+    T_ref = Phi_ref @ Wl
+    assert torch.allclose(torch.tril(T.cpu().double()), T_ref, **tol)
+    T_in = torch.tril(T) + junk.cuda()
+    G = ops.gemm(W_in, T_in, ta=True, alpha=-1.0, flags=ops.GEMM_A_UPPER | ops.GEMM_B_LOWER)
+    assert torch.allclose(G.cpu().double(), -(Wl.transpose(-1, -2) @ T_ref), **tol)
+
+
 def test_matmul_autograd_recursion(ops):
     g = _g(13)
     L = torch.randn(90, 90, generator=g, dtype=F64)           # lower-triangular operand, garbage above

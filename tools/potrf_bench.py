@@ -36,11 +36,24 @@ W = ops.trtri(L)
 Wbar = torch.tril(torch.randn(b, M, M, generator=g, dtype=torch.float64)).cuda()
 
 
-def chol_bwd():
+def chol_bwd_dense():
+    """round-1 form: Kbar = -1/2 W^T (Phi + Phi^T) W with the symmetrised S materialised (4/3 of a dense product)."""
     Bm = ops.gemm(Wbar, W, tb=True, flags=ops.GEMM_A_LOWER | ops.GEMM_B_UPPER)
     S = ops.chol_bwd_phi_sym(Bm)
     T = ops.gemm(S, W, flags=ops.GEMM_B_LOWER)
     return ops.gemm(W, T, ta=True, alpha=-0.5, flags=ops.GEMM_A_UPPER)
 
 
-print(f'chol adjoint (3 GEMMs)  {timeit(chol_bwd):8.1f} us')
+def chol_bwd():
+    """WhitenFn.backward: G = -W^T Phi W, every product triangular (2/3 of a dense product)."""
+    fl = ops.GEMM_C_LOWER | ops.GEMM_C_NOFILL
+    Phi = ops.gemm(Wbar, W, tb=True, flags=ops.GEMM_A_LOWER | ops.GEMM_B_UPPER | fl)
+    ops.scale_diag_(Phi, 0.5)
+    T = ops.gemm(Phi, W, flags=ops.GEMM_A_LOWER | ops.GEMM_B_LOWER | fl)
+    return ops.gemm(W, T, ta=True, alpha=-1.0, flags=ops.GEMM_A_UPPER | ops.GEMM_B_LOWER)
+
+
+G, Kb = chol_bwd(), chol_bwd_dense()
+print('G + G^T == 2 Kbar:', float(((G + G.transpose(-1, -2)) - 2 * Kb).abs().max() / Kb.abs().max()))
+print(f'chol adjoint, symmetrised S (round 1)  {timeit(chol_bwd_dense):8.1f} us')
+print(f'chol adjoint, triangular products      {timeit(chol_bwd):8.1f} us')
