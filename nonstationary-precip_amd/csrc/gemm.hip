@@ -165,6 +165,9 @@ struct TileLoader {
 // accumulation are float64.  This is the whitened projection A = L^-1 Kzx of the SVGP layer: the reference solves it
 // in float64 and rounds once; float32 accumulation of W Kzx loses 2e-4 at kappa(Kzz) ~ 1e6 (terms of size |W||K| ~ 80
 // cancel to O(1); tools/probes/whiten_precision.py), float64 accumulation reproduces the float64 solve to 3e-8.
+#ifndef NSGP_F64_DEPTH
+#define NSGP_F64_DEPTH 2
+#endif
 template <typename T, int BM, int BN, int BK, int MODE_A, int MODE_B, int EPI = 0, int KSC = 0, int PF = 0, int EDGE = 1,
           int MIX = 0>
 __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && sizeof(T) == 4) ? 3 : ((sizeof(T) == 8 && BM == 128 && BK == 32) ? 1 : 2)) void gemm_kernel(GemmArgs g, T alpha, const T* __restrict__ A,
@@ -301,8 +304,11 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && sizeof(T) == 4) ? 3 
 
     // per staging register set (PF2 keeps two tiles in flight): is the held tile a diagonal block of A / B, and its
     // k0 - row0 offsets
-    bool st_adiag[2] = {false, false}, st_bdiag[2] = {false, false};
-    int st_ad[2] = {0, 0}, st_bd[2] = {0, 0};
+    // DEEP > 0 (plain float64 products on whole tiles): the K loop keeps DEEP register sets of loads in flight, see below
+    constexpr int DEEP = (sizeof(T) == 8 && KSC == 0 && EDGE == 0 && PF == 0 && MIX == 0 && EPI == 0) ? NSGP_F64_DEPTH : 0;
+    constexpr int NSET = DEEP > 2 ? DEEP : 2;
+    bool st_adiag[NSET] = {}, st_bdiag[NSET] = {};
+    int st_ad[NSET] = {}, st_bd[NSET] = {};
     auto load_ks = [&](int64_t k0) __attribute__((always_inline)) {
         if (MODE_B == 0) {
             // every piece of this thread covers the same 4 k's: ONE load
@@ -409,7 +415,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && sizeof(T) == 4) ? 3 
     constexpr int KS0 = NKK / 2;                                     // first k-step that carries staging stores
     constexpr int PPS = (NPIECE + (NKK - KS0) - 1) / (NKK - KS0);    // pieces per k-step
     constexpr int FULLMASK = (1 << (TM * TN)) - 1;
-    auto ktile = [&](int buf, bool stage, auto tmask_c, auto masked_c, Frag4<T>* ra, Frag4<TB>* rb) __attribute__((always_inline)) {
+    auto ktile = [&](int buf, bool stage, auto tmask_c, auto masked_c, Frag4<T>* ra, Frag4<TB>* rb, int set = 0) __attribute__((always_inline)) {
         constexpr int tmask = decltype(tmask_c)::value;          // compile-time: a runtime mask makes every MFMA conditional
         const T* as = &As[buf][kr * LDA + wm0 + mc];             // and hipcc then keeps two copies of the accumulators
         const T* bs = &Bs[buf][kr * LDB + wn0 + mc];
@@ -429,7 +435,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && sizeof(T) == 4) ? 3 
             }
             if (ks >= KS0 && stage) {
 #pragma unroll
-                for (int q = (ks - KS0) * PPS; q < (ks - KS0 + 1) * PPS && q < NPIECE; ++q) store_piece(buf ^ 1, q, ra, rb, masked_c);
+                for (int q = (ks - KS0) * PPS; q < (ks - KS0 + 1) * PPS && q < NPIECE; ++q) store_piece(buf ^ 1, q, ra, rb, masked_c, set);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -476,7 +482,46 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && sizeof(T) == 4) ? 3 
         }
         return mk;
     };
-    if constexpr (PF2) {
+    if constexpr (DEEP > 0) {
+        // Latency-bound float64 products (the whitening chain: trtri levels, the Cholesky adjoint -- 3 x 1024^2, one
+        // round of 64 x 64 tiles, K ranges cut short by TWO triangular operands): a K-tile is 16 MFMAs per wave (0.4 us)
+        // while a load from the Infinity Cache takes 1-2 us, and the diagonal blocks at either end of a K range used to go
+        // through the one-tile-ahead generic loop.  Here EVERY K-tile (all are whole: EDGE == 0) runs in one loop with
+        // DEEP register sets: tile t issues the loads of tile t + DEEP into the set tile t came from and stores tile t + 1
+        // (loaded DEEP - 1 tiles ago) to LDS, diagonal blocks masked as they are stored.  All MFMA tiles run (the masked
+        // parts multiply zeros).  Unrolled by DEEP so the set indices are static.
+        static_assert(DEEP % 2 == 0, "the LDS buffer index is static only for an even depth");
+        if (nt > 0) {
+            Frag4<T> rsa[DEEP][PA];
+            Frag4<TB> rsb[DEEP][PB];
+            auto issue = [&](int t, int set) __attribute__((always_inline)) {
+                la.load_fast(rsa[set], (int64_t)t * BK);
+                lb.load_fast(rsb[set], (int64_t)t * BK);
+                const int64_t k0 = kbeg + (int64_t)t * BK;
+                st_adiag[set] = (aL || aU) && (k0 < m0 + BM) && (k0 + BK > m0);
+                st_bdiag[set] = (bL || bU) && (k0 < n0 + BN) && (k0 + BK > n0);
+                st_ad[set] = (int)(k0 - m0);
+                st_bd[set] = (int)(k0 - n0);
+            };
+            issue(0, 0);
+#pragma unroll
+            for (int d = 1; d < DEEP; ++d)
+                if (d < nt) issue(d, d);
+            sstore(0, rsa[0], rsb[0], 0);
+            __syncthreads();
+            for (int tb = 0; tb < nt; tb += DEEP) {
+#pragma unroll
+                for (int j = 0; j < DEEP; ++j) {
+                    const int t = tb + j;
+                    if (t >= nt) break;
+                    if (t + DEEP < nt) issue(t + DEEP, j);
+                    ktile(j & 1, t + 1 < nt, std::integral_constant<int, FULLMASK>{}, std::true_type{}, rsa[(j + 1) % DEEP],
+                          rsb[(j + 1) % DEEP], (j + 1) % DEEP);
+                    __syncthreads();
+                }
+            }
+        }
+    } else if constexpr (PF2) {
         if (nt > 0) {
             gload(0, ra0, rb0, 0);
             if (nt > 1) gload(1, ra1, rb1, 1);
