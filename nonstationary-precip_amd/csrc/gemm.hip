@@ -891,12 +891,14 @@ int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam,
     // hardware deals workgroups to the XCDs in strict rotation, so tiles of unequal length in flight stall the
     // dispatcher (measured: 611 us grouped vs 472 us in the row-major longest-first order, M=1024, n=40960).
     const char* grp = getenv("NSGP_GEMM_XCD_GROUP");
-    const bool group_ok = grp && grp[0] == '1';
+    const int grp_rows = grp ? atoi(grp) : 0;                       // 1: half the tile rows per group; r > 1: r rows per group
+    const bool group_ok = grp_rows >= 1;
     if (xcd_ok && group_ok && !(flags & NSGP_GEMM_C_LOWER) && g.ksplit == 1 && g.tiles_n >= 16 && g.tiles_m <= 64 &&
         !(flags & (NSGP_GEMM_B_LOWER | NSGP_GEMM_B_UPPER))) {
         const bool triA = flags & (NSGP_GEMM_A_LOWER | NSGP_GEMM_A_UPPER);
         int R = (int)g.tiles_m;
         if (triA && g.tiles_m >= 4 && g.tiles_m % 2 == 0) R = (int)g.tiles_m / 2;     // long rows first, short rows last
+        if (grp_rows > 1 && g.tiles_m % grp_rows == 0) R = grp_rows;
         g.xcd_group = R;
         ngrid_x = 8 * (g.tiles_m / R) * (cdiv64(g.tiles_n, 8) * R);
     } else if (xcd_ok && g.ksplit > 1 && ngrid * ngrid_y >= 64) {

@@ -300,14 +300,17 @@ __global__ __launch_bounds__(256) void pairwise_fwd_kernel(Op op, int64_t n1, in
     const int64_t jb = (int64_t)blockIdx.x * 64 * CPT;
     const int64_t j0 = jb + (int64_t)lane * CPT;
     const int64_t i0 = (int64_t)blockIdx.y * FWD_TI;
+    // column operands first (clamped indices, so every thread may load): their global-load latency overlaps the row
+    // operands' -- a tile is short (N = 4096: 1024 workgroups, all resident at once, ~20 us), two dependent
+    // latencies in front of the first store were a tenth of the launch
+    typename Op::P cols[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) cols[c] = op.fcol(b, j0 + c < n2 ? j0 + c : n2 - 1);
+    const T diag_add = diag_add_p ? diag_add_p[0] : diag_add_v;
     // row operands of the tile: computed once (one thread per row), then broadcast-read from LDS
     if (threadIdx.x < FWD_TI && i0 + threadIdx.x < n1) rows_s[threadIdx.x] = op.row(b, i0 + threadIdx.x);
     __syncthreads();
     if (j0 >= n2) return;
-    const T diag_add = diag_add_p ? diag_add_p[0] : diag_add_v;
-    typename Op::P cols[CPT];
-#pragma unroll
-    for (int c = 0; c < CPT; ++c) cols[c] = op.fcol(b, j0 + c < n2 ? j0 + c : n2 - 1);
     T* Kb = K + b * sK;
     const bool full = vec_ok && (j0 + CPT <= n2);
     const int rmax = (int)(n1 - i0 < FWD_TI ? n1 - i0 : FWD_TI);

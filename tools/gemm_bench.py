@@ -45,7 +45,8 @@ only = os.environ.get('ONLY')
 if only:
     cases = [c for c in cases if only in c[0]]
 envab = os.environ.get('ENVAB')
-variants = [('', None)] if not envab else [(f' [{envab}=0]', '0'), (f' [{envab}=1]', '1')]
+vals = os.environ.get('ENVVALS', '0,1').split(',')
+variants = [('', None)] if not envab else [(f' [{envab}={v}]', v) for v in vals]
 times = {(c[0], v[0]): [] for c in cases for v in variants}
 for r in range(rounds + 2):
     for name, fn, flops in cases:
