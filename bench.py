@@ -391,8 +391,8 @@ def main_cfg5(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--config', choices=('cfg4', 'cfg5'), default='cfg4',
                     help='cfg4 (default): BASELINE configs[3], the headline 2-layer M=1024 workload; cfg5: configs[4], the 3-layer '
