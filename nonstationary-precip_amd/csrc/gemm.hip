@@ -165,12 +165,18 @@ struct TileLoader {
 // accumulation are float64.  This is the whitened projection A = L^-1 Kzx of the SVGP layer: the reference solves it
 // in float64 and rounds once; float32 accumulation of W Kzx loses 2e-4 at kappa(Kzz) ~ 1e6 (terms of size |W||K| ~ 80
 // cancel to O(1); tools/probes/whiten_precision.py), float64 accumulation reproduces the float64 solve to 3e-8.
+#ifndef NSGP_MIX_WG3
+#define NSGP_MIX_WG3 0
+#endif
+#ifndef NSGP_MIX_DEEP
+#define NSGP_MIX_DEEP 1
+#endif
 #ifndef NSGP_F64_DEPTH
 #define NSGP_F64_DEPTH 2
 #endif
 template <typename T, int BM, int BN, int BK, int MODE_A, int MODE_B, int EPI = 0, int KSC = 0, int PF = 0, int EDGE = 1,
           int MIX = 0>
-__global__ __launch_bounds__(256, (BM == 128 && BN == 64 && sizeof(T) == 4) ? 3 : ((sizeof(T) == 8 && BM == 128 && BK == 32) ? 1 : 2)) void gemm_kernel(GemmArgs g, T alpha, const T* __restrict__ A,
+__global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || NSGP_MIX_WG3)) ? 3 : ((sizeof(T) == 8 && BM == 128 && BK == 32) ? 1 : 2)) void gemm_kernel(GemmArgs g, T alpha, const T* __restrict__ A,
                                                    const T* __restrict__ B, T beta, T* __restrict__ C,
                                                    T* __restrict__ slabs, Epi ep) {
     static_assert(MIX == 0 || (sizeof(T) == 8 && EPI == 1 && KSC == 0 && PF == 0), "MIX: float64 colstats projection only");
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && sizeof(T) == 4) ? 3 
     // per staging register set (PF2 keeps two tiles in flight): is the held tile a diagonal block of A / B, and its
     // k0 - row0 offsets
     // DEEP > 0 (plain float64 products on whole tiles): the K loop keeps DEEP register sets of loads in flight, see below
-    constexpr int DEEP = (sizeof(T) == 8 && KSC == 0 && EDGE == 0 && PF == 0 && MIX == 0 && EPI == 0) ? NSGP_F64_DEPTH : 0;
+    constexpr int DEEP = (sizeof(T) == 8 && KSC == 0 && EDGE == 0 && PF == 0 && ((MIX == 0 && EPI == 0) || (MIX != 0 && NSGP_MIX_DEEP))) ? NSGP_F64_DEPTH : 0;
     constexpr int NSET = DEEP > 2 ? DEEP : 2;
     bool st_adiag[NSET] = {}, st_bdiag[NSET] = {};
     int st_ad[NSET] = {}, st_bd[NSET] = {};
