@@ -171,6 +171,9 @@ struct TileLoader {
 #ifndef NSGP_MIX_DEEP
 #define NSGP_MIX_DEEP 1
 #endif
+#ifndef NSGP_F32_DEEP
+#define NSGP_F32_DEEP 0
+#endif
 #ifndef NSGP_F64_DEPTH
 #define NSGP_F64_DEPTH 2
 #endif
@@ -311,7 +314,8 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || N
     // per staging register set (PF2 keeps two tiles in flight): is the held tile a diagonal block of A / B, and its
     // k0 - row0 offsets
     // DEEP > 0 (plain float64 products on whole tiles): the K loop keeps DEEP register sets of loads in flight, see below
-    constexpr int DEEP = (sizeof(T) == 8 && KSC == 0 && EDGE == 0 && PF == 0 && ((MIX == 0 && EPI == 0) || (MIX != 0 && NSGP_MIX_DEEP))) ? NSGP_F64_DEPTH : 0;
+    constexpr int DEEP = (sizeof(T) == 8 && KSC == 0 && EDGE == 0 && PF == 0 && ((MIX == 0 && EPI == 0) || (MIX != 0 && NSGP_MIX_DEEP))) ? NSGP_F64_DEPTH
+                         : ((sizeof(T) == 4 && KSC == 0 && EDGE == 0 && NSGP_F32_DEEP > 0) ? NSGP_F32_DEEP : 0);
     constexpr int NSET = DEEP > 2 ? DEEP : 2;
     bool st_adiag[NSET] = {}, st_bdiag[NSET] = {};
     int st_ad[NSET] = {}, st_bd[NSET] = {};
@@ -563,7 +567,10 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || N
                 return true;
             };
             int r0 = 0, r1 = 0;
-            if (EDGE == 0 && !cL_partial) {
+            // (waves of a diagonal output tile of a lower-only product take the hot loop too and compute their whole 64 x 64
+            // block: sending them through the one-tile-ahead generic loop to skip the MFMA tiles above the diagonal held
+            // back the whole workgroup -- Wbar = tril(Abar Kzx^T): 482 -> 456 us)
+            if (EDGE == 0) {
                 while (r0 < nt && !regular(r0)) ++r0;
                 r1 = r0;
                 while (r1 < nt && regular(r1)) ++r1;
