@@ -174,6 +174,9 @@ struct TileLoader {
 #ifndef NSGP_F32_DEEP
 #define NSGP_F32_DEEP 0
 #endif
+#ifndef NSGP_F64_BK
+#define NSGP_F64_BK 16
+#endif
 #ifndef NSGP_F64_DEPTH
 #define NSGP_F64_DEPTH 2
 #endif
@@ -931,14 +934,14 @@ int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam,
     const char* pfe = getenv("NSGP_GEMM_PF");
     const bool one_round = (pfe && pfe[0] == '1') && ngrid * nb * g.ksplit <= 256 * 3;
     if (ekind != 0 && (g.ksplit != 1 || beta != T(0) || (flags & NSGP_GEMM_C_LOWER))) return -30;
-    const int64_t bnn = p.narrow ? 64 : bmn, bkk = (bmn == 128 ? 32 : 16);
+    const int64_t bnn = p.narrow ? 64 : bmn, bkk = (bmn == 128 ? 32 : ((sizeof(T) == 8 && ekind == 0 && !eks) ? NSGP_F64_BK : 16));
     // whole, vector-loadable tiles everywhere -> the variant without bounds code (EDGE = 0)
     const bool whole = g.vecA && g.vecB && M % bmn == 0 && N % bnn == 0 && K % bkk == 0 && g.kper % bkk == 0;
     // launch<BM, BN, MA, MB, EP, KS>(): the PF = 1 variant only exists for plain float64 kernels
     auto launch = [&](auto bm_c, auto bn_c, auto ma_c, auto mb_c, auto ep_c, auto ks_c) {
         constexpr int BM_ = decltype(bm_c)::value, BN_ = decltype(bn_c)::value, MA = decltype(ma_c)::value,
                       MB = decltype(mb_c)::value, EP = decltype(ep_c)::value, KSv = decltype(ks_c)::value;
-        constexpr int BKc = (BM_ == 128 ? 32 : 16);
+        constexpr int BKc = (BM_ == 128 ? 32 : ((sizeof(T) == 8 && EP == 0 && KSv == 0) ? NSGP_F64_BK : 16));
         constexpr int pa = (MA == 0 && sizeof(T) == 4) ? 1 : Mfma<T>::PAD;
         constexpr int pb = (MB == 0 && sizeof(T) == 4) ? 1 : Mfma<T>::PAD;
         constexpr size_t lds = 2 * BKc * ((BM_ + pa) + (BN_ + pb)) * sizeof(T);
