@@ -62,6 +62,16 @@ def run_split(dataset, random_state, args, device):
         frame = pd.DataFrame({'pred': (y_means.mean(0).cpu() * stdy + meany).numpy(),
                               'std': (y_var.mean(0).sqrt().cpu() * stdy).numpy(),
                               'lat': raw_x[:, 0], 'lon': raw_x[:, 1]})
+    if getattr(args, 'predict_all', False):
+        # predictions at every row of the CSV in the reference's results/*.csv layout (index, pred, std, lat, lon):
+        # what experiments/spatial_exp.py:252 reads back as results/f_mean_sigma_dgp2.csv
+        all_x = x_tr.to(device)
+        with torch.no_grad(), gpytorch.settings.num_likelihood_samples(args.samples):
+            _, a_means, a_var, _ = model.predict(DataLoader(TensorDataset(all_x, y_tr.to(device)), batch_size=args.batch))
+        raw_all = (x_tr * stdx + meanx).numpy()
+        args.frame_all = pd.DataFrame({'pred': (a_means.mean(0).cpu() * stdy + meany).numpy(),
+                                       'std': (a_var.mean(0).sqrt().cpu() * stdy).numpy(),
+                                       'lat': raw_all[:, 0], 'lon': raw_all[:, 1]})
     return rmse_test, nlpd_test, float(loss.detach()), frame
 
 
