@@ -827,9 +827,13 @@ template <typename T> Plan make_plan(int64_t M, int64_t N, int64_t K, int64_t nb
     double best_cost = 1e300;
     for (int64_t ks = 1; ks <= maxks; ++ks) {
         const int64_t rounds = cdiv64(tiles * ks, slots);
-        // K-tiles of MFMA work per round + per-block fixed cost (prologue/epilogue ~ 6 K-tiles) + the
-        // split's slab write/read (in K-tile units: one 128x128 fp32 slab ~ 2 K-tiles of time)
-        const double cost = (double)rounds * ((double)cdiv64(ktiles, ks) + 6.0) + (ks > 1 ? 2.0 * ks / 4.0 : 0.0);
+        // K-tiles of MFMA work per round + per-block fixed cost (prologue/epilogue ~ 6 K-tiles) + the split's slab
+        // write/read.  One unit is ~1.3 us (measured: 5 rounds x 70 units = 455 us); ks slabs of M x N x nb elements
+        // are written and read back once, at ~4 TB/s: 2 ks M N nb sizeof(T) / 4e12 s.  (The old constant term priced a
+        // 1024 x 1024 output; an n-wide output such as Kzxbar = W^T Abar at n = 5120 -- one rank of eight -- was split
+        // three ways and paid 25 us of reduce for it: 138 us against 80 us un-split.)
+        const double slab_units = ks > 1 ? (double)ks * (double)M * (double)N * (double)nb * sizeof(T) / 2.6e6 : 0.0;
+        const double cost = (double)rounds * ((double)cdiv64(ktiles, ks) + 6.0) + slab_units;
         if (cost < best_cost - 1e-9) { best_cost = cost; best_ks = ks; }
     }
     p.kper = cdiv64(cdiv64(K, best_ks), 32) * 32;
