@@ -233,6 +233,15 @@ int nsgp_svgp_tri_gemm_colstats_f32(const float* L, int trans, const float* X, c
 int nsgp_svgp_tri_gemm_colstats_f64(const double* L, int trans, const double* X, const double* rowvec, int64_t batch,
                                     int64_t M, int64_t n, double* Y, double* part_dot, double* part_sq,
                                     void* stream);
+/* the same launches with the partial buffers laid out with `part_rows` tile rows per batch element (>= the launch's own
+ * tile rows; rows it does not fill are the caller's to zero): lets two launches with different tile heights -- the
+ * float64-accumulating product below and the float32 product that follows it -- share one set of buffers */
+int nsgp_svgp_tri_gemm_colstats_rows_f32(const float* L, int trans, const float* X, const float* rowvec, int64_t batch,
+                                         int64_t M, int64_t n, float* Y, float* part_dot, float* part_sq,
+                                         int64_t part_rows, void* stream);
+int nsgp_svgp_tri_gemm_colstats_rows_f64(const double* L, int trans, const double* X, const double* rowvec, int64_t batch,
+                                         int64_t M, int64_t n, double* Y, double* part_dot, double* part_sq,
+                                         int64_t part_rows, void* stream);
 /* The whitened projection A = L^-1 Kzx with float64 arithmetic on float32 data: Y[b] = W[b] X[b], W float64 lower
  * triangular (= chol(Kzz)^-1), X / Y / rowvec / partials float32; float64 MFMA accumulation.  This is what the
  * reference computes -- gpytorch VariationalStrategy.forward solves L A = Kzx.double() and casts A back (SURVEY A.3;
@@ -240,6 +249,7 @@ int nsgp_svgp_tri_gemm_colstats_f64(const double* L, int trans, const double* X,
  * The kernel fills ceil(M / 128) tile rows (nsgp_svgp_f64acc_tiles) of partial buffers laid out with `part_rows`
  * (>= that number) tile rows per batch element; the caller zeroes the rows it does not fill. */
 size_t nsgp_svgp_f64acc_tiles(int64_t M);
+size_t nsgp_svgp_f64acc_tiles_for(int64_t M, int64_t n, int64_t batch);   /* tile rows the launch uses for this shape (64- or 128-row tiles) */
 int nsgp_svgp_tri_gemm_colstats_f64acc(const double* W, const float* X, const float* rowvec, int64_t batch, int64_t M,
                                        int64_t n, float* Y, float* part_dot, float* part_sq, int64_t part_rows,
                                        void* stream);

@@ -87,6 +87,7 @@ struct Epi {
     void *p0, *p1;
     int modeA, modeB;       // operand modes of the instantiated variant (any strides are valid in either mode;
                             // the mode only decides the vector-load direction)
+    int part_rows;          // kind 1: tile rows per batch element in the partial buffers (0 = the launch's own tile rows)
 };
 
 // 4-element register fragment loaded from global
@@ -903,7 +904,7 @@ int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam,
     int64_t ngrid_x = ngrid, ngrid_y = nb * g.ksplit;
     g.xcd_group = 0;
     g.xcd_chunk = 0;
-    g.part_rows = 0;
+    g.part_rows = epi ? epi->part_rows : 0;
     g.nbk = (int)(nb * g.ksplit);
     const char* no_xcd = getenv("NSGP_GEMM_NO_XCD");              // A/B switches for tools/gemm_bench.py
     const bool xcd_ok = !(no_xcd && no_xcd[0] == '1');
@@ -1013,15 +1014,27 @@ int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam,
 
 // ---- SVGP projection GEMMs with fused epilogues (include/nsgp.h, section K6) ---------------------------
 namespace {
+// tile rows of the float64-accumulating projection for a given shape (see tri_gemm_colstats_f64acc_impl)
+static inline int f64acc_tile_rows(int64_t M, int64_t n, int64_t batch) {
+    return cdiv64(M, 128) * cdiv64(n, NSGP_F64ACC_BN) * batch < 512 ? 64 : 128;
+}
+
 template <typename T>
 int tri_gemm_colstats_impl(const T* L, int trans, const T* X, const T* rowvec, int64_t batch, int64_t M, int64_t n,
-                           T* Y, T* part_dot, T* part_sq, void* stream) {
+                           T* Y, T* part_dot, T* part_sq, void* stream, int64_t part_rows = 0) {
     if (!L) return -1; if (trans != 0 && trans != 1) return -2; if (!X) return -3;
     if (batch < 0) return -5; if (M < 0) return -6; if (n < 0) return -7; if (!Y) return -8; if (!part_sq) return -10;
     if (batch == 0 || M == 0 || n == 0) return 0;
     Epi ep{};
     ep.kind = 1; ep.rv = rowvec; ep.p0 = part_dot; ep.p1 = part_sq; ep.modeA = trans ? 1 : 0; ep.modeB = 1;
+    ep.part_rows = (int)part_rows;
     const int flags = (trans ? NSGP_GEMM_A_UPPER : NSGP_GEMM_A_LOWER) | NSGP_GEMM_NO_SPLITK;
+    int64_t tiles_m = 0;
+    if (part_rows > 0) {                                  // the caller's buffers must hold this launch's tile rows
+        Plan p = make_plan<T>(M, n, M, batch, flags, !(sizeof(T) == 8));
+        if (part_rows < cdiv64(M, p.big ? 128 : 64)) return -12;
+    }
+    (void)tiles_m;
     return gemm_impl<T>(M, n, M, T(1), L, trans ? 1 : M, trans ? M : 1, M * M, 0, X, n, 1, M * n, 0, T(0), Y, n, M * n, 0,
                         batch, 1, flags, nullptr, 0, stream, &ep);
 }
@@ -1059,7 +1072,10 @@ int tri_gemm_colstats_f64acc_impl(const double* W, const float* X, const float* 
     if (!W) return -1; if (!X) return -2; if (batch < 0) return -4; if (M < 0) return -5; if (n < 0) return -6;
     if (!Y) return -7; if (!part_sq) return -9;
     if (batch == 0 || M == 0 || n == 0) return 0;
-    constexpr int BM_ = 128, BN_ = NSGP_F64ACC_BN, BK_ = NSGP_F64ACC_BK;
+    constexpr int BN_ = NSGP_F64ACC_BN, BK_ = NSGP_F64ACC_BK;
+    // 128-row tiles, or 64-row tiles when the 128-row grid would not fill one round of the chip (a rank's share of the
+    // hidden layer at 4-8 GPUs, n = 512..1024: 128 workgroups of up to 64 K-tiles each were latency-bound, 96 us)
+    const int BM_ = f64acc_tile_rows(M, n, batch);
     if (part_rows < cdiv64(M, BM_)) return -10;
     GemmArgs g{};
     g.M = M; g.N = n; g.K = M;
@@ -1077,21 +1093,22 @@ int tri_gemm_colstats_f64acc_impl(const double* W, const float* X, const float* 
     Epi ep{};
     ep.kind = 1; ep.rv = rowvec; ep.p0 = part_dot; ep.p1 = part_sq; ep.modeA = 0; ep.modeB = 1;
     const bool whole = g.vecA && g.vecB && M % BM_ == 0 && n % BN_ == 0 && M % BK_ == 0;
-    constexpr size_t lds = 2 * BK_ * ((BM_ + Mfma<double>::PAD) + (BN_ + Mfma<double>::PAD)) * sizeof(double);
     dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)batch, 1);
     hipStream_t st = (hipStream_t)stream;
     // the kernel takes its B / C pointers as double* and reinterprets them (MIX = 1)
     const double* Bp = reinterpret_cast<const double*>(X);
     double* Cp = reinterpret_cast<double*>(Y);
-    if (whole) {
-        nsgp_opt_in_lds((const void*)gemm_kernel<double, BM_, BN_, BK_, 0, 1, 1, 0, 0, 0, 1>, lds);
-        hipLaunchKernelGGL((gemm_kernel<double, BM_, BN_, BK_, 0, 1, 1, 0, 0, 0, 1>), grid, dim3(256), lds, st, g, 1.0, W, Bp,
-                           0.0, Cp, (double*)nullptr, ep);
-    } else {
-        nsgp_opt_in_lds((const void*)gemm_kernel<double, BM_, BN_, BK_, 0, 1, 1, 0, 0, 1, 1>, lds);
-        hipLaunchKernelGGL((gemm_kernel<double, BM_, BN_, BK_, 0, 1, 1, 0, 0, 1, 1>), grid, dim3(256), lds, st, g, 1.0, W, Bp,
-                           0.0, Cp, (double*)nullptr, ep);
-    }
+    auto go = [&](auto bm_c, auto edge_c) {
+        constexpr int BMc = decltype(bm_c)::value, EDGEc = decltype(edge_c)::value;
+        constexpr size_t lds = 2 * BK_ * ((BMc + Mfma<double>::PAD) + (BN_ + Mfma<double>::PAD)) * sizeof(double);
+        nsgp_opt_in_lds((const void*)gemm_kernel<double, BMc, BN_, BK_, 0, 1, 1, 0, 0, EDGEc, 1>, lds);
+        hipLaunchKernelGGL((gemm_kernel<double, BMc, BN_, BK_, 0, 1, 1, 0, 0, EDGEc, 1>), grid, dim3(256), lds, st, g, 1.0, W,
+                           Bp, 0.0, Cp, (double*)nullptr, ep);
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using B64 = std::integral_constant<int, 64>; using B128 = std::integral_constant<int, 128>;
+    if (BM_ == 128) { if (whole) go(B128{}, I0{}); else go(B128{}, I1{}); }
+    else { if (whole) go(B64{}, I0{}); else go(B64{}, I1{}); }
     return nsgp_launch_status();
 }
 }  // namespace
@@ -1099,6 +1116,9 @@ int tri_gemm_colstats_f64acc_impl(const double* W, const float* X, const float* 
 extern "C" {
 
 size_t nsgp_svgp_f64acc_tiles(int64_t M) { return M > 0 ? (size_t)cdiv64(M, 128) : 0; }
+size_t nsgp_svgp_f64acc_tiles_for(int64_t M, int64_t n, int64_t batch) {
+    return (M > 0 && n > 0 && batch > 0) ? (size_t)cdiv64(M, f64acc_tile_rows(M, n, batch)) : 0;
+}
 int nsgp_svgp_tri_gemm_colstats_f64acc(const double* W, const float* X, const float* rowvec, int64_t batch, int64_t M,
                                        int64_t n, float* Y, float* part_dot, float* part_sq, int64_t part_rows,
                                        void* stream) {
@@ -1143,6 +1163,16 @@ int nsgp_svgp_tri_gemm_colstats_f64(const double* L, int trans, const double* X,
                                     int64_t M, int64_t n, double* Y, double* part_dot, double* part_sq,
                                     void* stream) {
     return tri_gemm_colstats_impl<double>(L, trans, X, rowvec, batch, M, n, Y, part_dot, part_sq, stream);
+}
+int nsgp_svgp_tri_gemm_colstats_rows_f32(const float* L, int trans, const float* X, const float* rowvec, int64_t batch,
+                                         int64_t M, int64_t n, float* Y, float* part_dot, float* part_sq,
+                                         int64_t part_rows, void* stream) {
+    return tri_gemm_colstats_impl<float>(L, trans, X, rowvec, batch, M, n, Y, part_dot, part_sq, stream, part_rows);
+}
+int nsgp_svgp_tri_gemm_colstats_rows_f64(const double* L, int trans, const double* X, const double* rowvec, int64_t batch,
+                                         int64_t M, int64_t n, double* Y, double* part_dot, double* part_sq,
+                                         int64_t part_rows, void* stream) {
+    return tri_gemm_colstats_impl<double>(L, trans, X, rowvec, batch, M, n, Y, part_dot, part_sq, stream, part_rows);
 }
 int nsgp_svgp_abar_f32(const float* Lq, const float* C, const float* A, const float* m, const float* gmean,
                        const float* gvar, int64_t batch, int64_t M, int64_t n, float* Abar, void* stream) {

@@ -509,19 +509,18 @@ def svgp_project(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None):
                 or W64f.device != ref.device:
             raise BackendError('svgp_project: W64f must be the float64 (b,M,M) W of a float32 layer')
         W64f = _c(W64f)
-        T64 = int(lib.nsgp_svgp_f64acc_tiles(M))            # 128-row tiles: never more than the float32 plan's T
-        if T64 > T:
-            raise BackendError('svgp_project: tile-row mismatch between the float64 and float32 projection plans')
-        # tile rows the float64 kernel does not fill (small M only: 64-row float32 tiles vs its 128-row tiles) stay zero
-        part = (torch.zeros if T64 < T else torch.empty)((3, batch, max(T, 1), n), dtype=ref.dtype, device=ref.device)
+        T64 = int(lib.nsgp_svgp_f64acc_tiles_for(M, n, batch))    # 128-row tiles, 64-row ones for small grids
+        T32, T = T, max(T, T64)
+        # tile rows one of the two kernels does not fill (their tile heights differ for some shapes) stay zero
+        part = (torch.zeros if T64 != T32 else torch.empty)((3, batch, max(T, 1), n), dtype=ref.dtype, device=ref.device)
         _timed(lambda: _lib.call('nsgp_svgp_tri_gemm_colstats_f64acc', _p(W64f), _p(Kzx), _p(m), batch, M, n, _p(A),
                                  _p(part[0]), _p(part[1]), T, st), flops, 'f64acc')
     else:
         part = torch.empty((3, batch, max(T, 1), n), dtype=ref.dtype, device=ref.device)
         _timed(lambda: _lib.call(f'nsgp_svgp_tri_gemm_colstats_{sfx}', _p(W), 0, _p(Kzx), _p(m), batch, M, n, _p(A),
                                  _p(part[0]), _p(part[1]), st), flops, ref.dtype)
-    _timed(lambda: _lib.call(f'nsgp_svgp_tri_gemm_colstats_{sfx}', _p(Lq), 1, _p(A), None, batch, M, n, _p(C),
-                             None, _p(part[2]), st), flops, ref.dtype)
+    _timed(lambda: _lib.call(f'nsgp_svgp_tri_gemm_colstats_rows_{sfx}', _p(Lq), 1, _p(A), None, batch, M, n, _p(C),
+                             None, _p(part[2]), T, st), flops, ref.dtype)
     mean = torch.empty((batch, n), dtype=ref.dtype, device=ref.device)
     var = torch.empty_like(mean)
     if affine is None:
