@@ -191,7 +191,6 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || N
     using TC = std::conditional_t<MIX != 0, float, T>;          // element type of C / rv / partials in memory
     using MF = Mfma<T>;
     constexpr int MT = MF::MT, KS = MF::KS, NKK = BK / KS;
-    constexpr int KCH = NKK < 8 ? NKK : 8;                      // k-steps whose fragments are prefetched together (PF2)
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int TM = WM / MT, TN = WN / MT;
     constexpr int PADA = (MODE_A == 0 && sizeof(T) == 4) ? 1 : MF::PAD;
@@ -304,18 +303,13 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || N
     lb.init(tid, Bb, n0, g.sbn, g.sbk, kbeg);
     const int mrem = (int)(g.M - m0 < BM ? g.M - m0 : BM), nrem = (int)(g.N - n0 < BN ? g.N - n0 : BN);
 
-    // PF = 1 (float64, grids of at most one round): the tile is small (16 MFMAs per wave and K-tile, 0.25 us),
-    // one K-tile of prefetch does not cover a global-load latency, so TWO K-tiles are kept in flight in two
-    // register sets.  It costs a wave of occupancy (3 -> 2 per SIMD), which multi-round grids need more
-    // (N=16384 potrf: 39 ms without, 51 ms with), so those keep PF = 0.
-    constexpr bool PF2 = PF != 0 && sizeof(T) == 8 && KSC == 0;
-    Frag4<T> ra0[PA], ra1[PF2 ? PA : 1];
-    Frag4<TB> rb0[PB], rb1[PF2 ? PB : 1];
+    Frag4<T> ra0[PA];
+    Frag4<TB> rb0[PB];
     Frag4<T> rks[KSC ? PB : 1];
     const T* ksb = KSC ? reinterpret_cast<const T*>(ep.ks) + bb * g.K : nullptr;
     const bool ks_vec = KSC && ((uintptr_t)ksb % (4 * sizeof(T)) == 0);
 
-    // per staging register set (PF2 keeps two tiles in flight): is the held tile a diagonal block of A / B, and its
+    // per staging register set (the float64 loop keeps two tiles in flight): is the held tile a diagonal block of A / B, and its
     // k0 - row0 offsets
     // DEEP > 0 (plain float64 products on whole tiles): the K loop keeps DEEP register sets of loads in flight, see below
     constexpr int DEEP = (sizeof(T) == 8 && KSC == 0 && EDGE == 0 && PF == 0 && ((MIX == 0 && EPI == 0) || (MIX != 0 && NSGP_MIX_DEEP))) ? NSGP_F64_DEPTH
@@ -392,30 +386,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || N
     };
 
     const int kr = MF::krow(lane), mc = MF::mcol(lane);
-    // old-style compute (fragments of KCH k-steps, then their MFMAs): kept for the float64 two-tiles-in-flight variant
-    auto compute = [&](int buf) __attribute__((always_inline)) {
-        const T* as = &As[buf][kr * LDA + wm0 + mc];
-        const T* bs = &Bs[buf][kr * LDB + wn0 + mc];
-#pragma unroll
-        for (int kc = 0; kc < NKK; kc += KCH) {
-            T af[KCH][TM], bf[KCH][TN];
-#pragma unroll
-            for (int kk = 0; kk < KCH; ++kk) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) af[kk][i] = as[(kc + kk) * KS * LDA + i * MT];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bf[kk][j] = bs[(kc + kk) * KS * LDB + j * MT];
-            }
-#pragma unroll
-            for (int kk = 0; kk < KCH; ++kk)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(af[kk][i], bf[kk][j], acc[i][j]);
-        }
-    };
-
-    // ---- software-pipelined K-tile (the main loop of every variant but PF2) ----------------------------------------
+    // ---- software-pipelined K-tile (the main loop of every variant) ------------------------------------------------
     // One wave must keep its SIMD's matrix pipe busy on its own: the two workgroups of a CU run the same program and
     // fall into step, so whatever one wave exposes (LDS read latency in front of every k-step, the staging stores
     // and the barrier at the end of a K-tile) the other exposes at the same moment (round 1: pipe 66-73 % busy,
@@ -472,7 +443,6 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || N
             for (int j = 0; j < TN; ++j)
                 if (n0 + wn0 + j * MT <= m0 + wm0 + (i + 1) * MT - 1) cmask_tile |= 1 << (i * TN + j);
     }
-    const bool cL_partial = cmask_tile != FULLMASK;      // a wave of a diagonal output tile with MFMA tiles to skip
     auto tile_mask = [&](int64_t k0) __attribute__((always_inline)) {
         int mk = cmask_tile;
         if (aL || aU) {
@@ -533,26 +503,6 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || N
                           rsb[(j + 1) % DEEP], (j + 1) % DEEP);
                     __syncthreads();
                 }
-            }
-        }
-    } else if constexpr (PF2) {
-        if (nt > 0) {
-            gload(0, ra0, rb0, 0);
-            if (nt > 1) gload(1, ra1, rb1, 1);
-            sstore(0, ra0, rb0, 0);
-            __syncthreads();
-            for (int t = 0; t < nt; t += 2) {
-                // even step: set 0 is free (stored), set 1 holds tile t+1
-                if (t + 2 < nt) gload(t + 2, ra0, rb0, 0);
-                compute(0);
-                if (t + 1 < nt) sstore(1, ra1, rb1, 1);
-                __syncthreads();
-                if (t + 1 >= nt) break;
-                // odd step: set 1 is free, set 0 holds tile t+2
-                if (t + 3 < nt) gload(t + 3, ra1, rb1, 1);
-                compute(1);
-                if (t + 2 < nt) sstore(0, ra0, rb0, 0);
-                __syncthreads();
             }
         }
     } else {
@@ -933,16 +883,11 @@ int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam,
     if (epi) ep = *epi;
     if (tiles_m_out) *tiles_m_out = g.tiles_m;
     const int ekind = ep.kind, eks = ep.ks != nullptr;
-    // The round-1 "two register sets, old loop" variant (PF = 1) for single-round float64 grids is no longer selected: the
-    // software-pipelined loop with two K-tiles of loads in flight measures the same (tools/potrf_bench.py: 3 x 1024^3
-    // Cholesky adjoint 384 vs 400 us).  NSGP_GEMM_PF=1 selects it for A/B timing.
-    const char* pfe = getenv("NSGP_GEMM_PF");
-    const bool one_round = (pfe && pfe[0] == '1') && ngrid * nb * g.ksplit <= 256 * 3;
     if (ekind != 0 && (g.ksplit != 1 || beta != T(0) || (flags & NSGP_GEMM_C_LOWER))) return -30;
     const int64_t bnn = p.narrow ? 64 : bmn, bkk = (bmn == 128 ? 32 : ((sizeof(T) == 8 && ekind == 0 && !eks) ? NSGP_F64_BK : 16));
     // whole, vector-loadable tiles everywhere -> the variant without bounds code (EDGE = 0)
     const bool whole = g.vecA && g.vecB && M % bmn == 0 && N % bnn == 0 && K % bkk == 0 && g.kper % bkk == 0;
-    // launch<BM, BN, MA, MB, EP, KS>(): the PF = 1 variant only exists for plain float64 kernels
+    // launch<BM, BN, MA, MB, EP, KS>()  (the PF template slot, round 1's separate two-tiles-in-flight loop, is always 0 now)
     auto launch = [&](auto bm_c, auto bn_c, auto ma_c, auto mb_c, auto ep_c, auto ks_c) {
         constexpr int BM_ = decltype(bm_c)::value, BN_ = decltype(bn_c)::value, MA = decltype(ma_c)::value,
                       MB = decltype(mb_c)::value, EP = decltype(ep_c)::value, KSv = decltype(ks_c)::value;
@@ -954,13 +899,6 @@ int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam,
             nsgp_opt_in_lds((const void*)kern, lds);
             hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g, alpha, A, B, beta, C, slabs, ep);
         };
-        if constexpr (sizeof(T) == 8 && EP == 0 && KSv == 0 && BM_ == 64) {
-            if (one_round) {
-                if (whole) go(gemm_kernel<T, BM_, BN_, BKc, MA, MB, 0, 0, 1, 0>);
-                else go(gemm_kernel<T, BM_, BN_, BKc, MA, MB, 0, 0, 1, 1>);
-                return;
-            }
-        }
         if (whole) go(gemm_kernel<T, BM_, BN_, BKc, MA, MB, EP, KSv, 0, 0>);
         else go(gemm_kernel<T, BM_, BN_, BKc, MA, MB, EP, KSv, 0, 1>);
     };
