@@ -422,6 +422,9 @@ def main():
     ap.add_argument('--fp32-whiten', action='store_true',
                     help="analysis only: round 1's arithmetic -- the whitened projection A = L^-1 Kzx as an fp32 product "
                          '(settings.whiten_matmul_f64(False)); misses the 1e-4 posterior-mean bound at this shape')
+    ap.add_argument('--fuse-kzx', action='store_true',
+                    help='analysis only: generate the Kzx tiles inside the loader of the forward projection instead of '
+                         'materialising Kzx (settings.fuse_kzx(True)): less HBM traffic, slower product')
     ap.add_argument('--rank-share', type=int, default=1, metavar='G',
                     help='analysis only: run ONE rank\'s share of a G-rank job on this GPU (rows [0, 4096/G) of every '
                          'minibatch, the objective scaled as on rank 0 of G; no collective).  The JSON line is marked '
@@ -550,7 +553,7 @@ def main():
         torch.cuda.synchronize()
 
     with settings.num_likelihood_samples(S_SAMPLES), settings.eps_provider(eps), \
-            settings.whiten_matmul_f64(not args.fp32_whiten):
+            settings.whiten_matmul_f64(not args.fp32_whiten), settings.fuse_kzx(args.fuse_kzx):
         use_graph = not args.no_graph
         x_in.copy_(xs[0]); y_in.copy_(ys[0])
         with torch.no_grad():
@@ -655,6 +658,8 @@ def main():
             'iterations_per_sec': round(args.steps / elapsed, 3),
             'rows_per_sec': round(gbatch * args.steps / elapsed, 1),
             **({'analysis_split_graph': 'two graph replays per step, as in an N>1 run'} if args.split_graph else {}),
+            **({'analysis_fuse_kzx': 'Kzx generated inside the forward projection (never materialised in the forward pass)'}
+               if args.fuse_kzx else {}),
             **({'analysis_fp32_whiten': 'fp32 whitening product (round-1 arithmetic): NOT the shipped precision'}
                if args.fp32_whiten else {}),
             **({'analysis_rehearse_rccl': 'one-rank RCCL group, every collective of the N>1 step issued'} if rehearse else {}),

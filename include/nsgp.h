@@ -249,7 +249,19 @@ int nsgp_svgp_tri_gemm_colstats_rows_f64(const double* L, int trans, const doubl
  * The kernel fills ceil(M / 128) tile rows (nsgp_svgp_f64acc_tiles) of partial buffers laid out with `part_rows`
  * (>= that number) tile rows per batch element; the caller zeroes the rows it does not fill. */
 size_t nsgp_svgp_f64acc_tiles(int64_t M);
-size_t nsgp_svgp_f64acc_tiles_for(int64_t M, int64_t n, int64_t batch);   /* tile rows the launch uses for this shape (64- or 128-row tiles) */
+size_t nsgp_svgp_f64acc_tiles_for(int64_t M, int64_t n, int64_t batch);
+/* The same product with the Kzx operand NEVER MATERIALISED: the loader generates each tile
+ *   Kzx[b](k, j) = os[b] exp(-1/2 sum_d ((z[b][k][d] - x[j][d]) / ls[b][d])^2)
+ * from the inducing points z (batch, M, D), the inputs x (n, D) shared (sx = 0) or (batch, n, D) (sx = n D), ls (batch, D)
+ * and os (batch,) -- the arithmetic of nsgp_rbf_build_fwd_f32, operation for operation, so A equals the materialised
+ * product bit for bit.  Replaces the (M x n) round trip of Kzx through HBM behind
+ * /root/reference/models/dgps.py:44-51 ("fused with the RBF build of Kxz tiles").  Whole tiles only:
+ * nsgp_svgp_kzx_gemm_supported() says whether a shape qualifies (D <= 4, M a multiple of the tile rows, n of 64,
+ * 32-byte aligned W); -11 otherwise. */
+int nsgp_svgp_kzx_gemm_supported(const double* W, int64_t M, int64_t n, int64_t batch, int D);
+int nsgp_svgp_kzx_gemm_colstats_f64acc(const double* W, const float* z, const float* x, int64_t sx, const float* ls,
+                                       const float* os, int D, const float* rowvec, int64_t batch, int64_t M, int64_t n,
+                                       float* Y, float* part_dot, float* part_sq, int64_t part_rows, void* stream);   /* tile rows the launch uses for this shape (64- or 128-row tiles) */
 int nsgp_svgp_tri_gemm_colstats_f64acc(const double* W, const float* X, const float* rowvec, int64_t batch, int64_t M,
                                        int64_t n, float* Y, float* part_dot, float* part_sq, int64_t part_rows,
                                        void* stream);

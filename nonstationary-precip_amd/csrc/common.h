@@ -73,6 +73,8 @@ template <> __device__ __forceinline__ double t_rsqrt<double>(double x) {
 template <typename T> __device__ __forceinline__ T t_fsqrt(T x);
 template <> __device__ __forceinline__ float t_fsqrt<float>(float x) { return __builtin_amdgcn_sqrtf(x); }
 template <> __device__ __forceinline__ double t_fsqrt<double>(double x) { return sqrt(x); }
+__device__ __forceinline__ float t_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double t_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 template <typename T> __device__ __forceinline__ T t_fexp(T x);      // exp(x), x <= 0 on this path
 template <> __device__ __forceinline__ float t_fexp<float>(float x) {
     return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);

@@ -88,7 +88,14 @@ struct Epi {
     int modeA, modeB;       // operand modes of the instantiated variant (any strides are valid in either mode;
                             // the mode only decides the vector-load direction)
     int part_rows;          // kind 1: tile rows per batch element in the partial buffers (0 = the launch's own tile rows)
+    // MIX = 2: the B operand is never read -- B(k, n) = os[b] exp(-1/2 |z_k / ls[b] - x_n / ls[b]|^2) is generated in the
+    // loader from the inducing points z (batch, K, D), the inputs x (n, D) or (batch, n, D) (kx_sx = batch stride),
+    // ls (batch, D), os (batch): the arithmetic of pairwise.hip's RbfOp, operation for operation
+    const float *kz, *kx, *kls, *kos;
+    int kD;
+    int64_t kx_sx;
 };
+constexpr int KGEN_DMAX = 4;   // input dimensions the generated-operand loader keeps in registers
 
 // 4-element register fragment loaded from global
 template <typename T> struct Frag4 { T v[4]; };
@@ -187,6 +194,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || N
                                                    const T* __restrict__ B, T beta, T* __restrict__ C,
                                                    T* __restrict__ slabs, Epi ep) {
     static_assert(MIX == 0 || (sizeof(T) == 8 && EPI == 1 && KSC == 0 && PF == 0), "MIX: float64 colstats projection only");
+    static_assert(MIX != 2 || (EDGE == 0 && MODE_B == 1), "MIX = 2 (generated Kzx operand): whole tiles, n-contiguous pieces");
     using TB = std::conditional_t<MIX != 0, float, T>;          // element type of B in memory
     using TC = std::conditional_t<MIX != 0, float, T>;          // element type of C / rv / partials in memory
     using MF = Mfma<T>;
@@ -301,6 +309,23 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || N
     TileLoader<TB, MODE_B, BN, BK, PB> lb;
     la.init(tid, Ab, m0, g.sam, g.sak, kbeg);
     lb.init(tid, Bb, n0, g.sbn, g.sbk, kbeg);
+    // MIX = 2: this thread's four columns x_n / ls (fixed for the whole K loop), the GP's lengthscales and output scale
+    [[maybe_unused]] float kgxs[4][KGEN_DMAX], kgls[KGEN_DMAX], kgos = 0.f;
+    [[maybe_unused]] const float* kgz = nullptr;
+    [[maybe_unused]] int kgD = 0;
+    if constexpr (MIX == 2) {
+        kgD = ep.kD;
+        kgz = ep.kz + bb * g.K * kgD;
+        kgos = ep.kos[bb];
+#pragma unroll
+        for (int d = 0; d < KGEN_DMAX; ++d) kgls[d] = d < kgD ? ep.kls[bb * kgD + d] : 1.f;
+        const float* xb = ep.kx + bb * ep.kx_sx;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int d = 0; d < KGEN_DMAX; ++d)
+                kgxs[e][d] = d < kgD ? xb[(n0 + lb.prow(0) + e) * kgD + d] / kgls[d] : 0.f;
+    }
     const int mrem = (int)(g.M - m0 < BM ? g.M - m0 : BM), nrem = (int)(g.N - n0 < BN ? g.N - n0 : BN);
 
     Frag4<T> ra0[PA];
@@ -353,6 +378,32 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || N
         st_ad[set] = (int)(k0 - m0);
         st_bd[set] = (int)(k0 - n0);
         if constexpr (KSC != 0) load_ks(k0);
+    };
+    // MIX = 2: turn a staged piece of z rows into the four operand values B(k, n .. n + 3), in two halves so that the
+    // arithmetic (a division per coordinate, two exp) rides under two different MFMA groups of the K-tile
+    [[maybe_unused]] float kzs[PB][KGEN_DMAX];
+    [[maybe_unused]] Frag4<TB> kval[PB];
+    auto kgen_half = [&](Frag4<TB>* rb, int half) __attribute__((always_inline)) {
+        if constexpr (MIX == 2) {
+#pragma unroll
+            for (int p = 0; p < PB; ++p) {
+                if (half == 0) {
+#pragma unroll
+                    for (int d = 0; d < KGEN_DMAX; ++d) kzs[p][d] = d < kgD ? rb[p].v[d] / kgls[d] : 0.f;
+                }
+#pragma unroll
+                for (int e = 2 * half; e < 2 * half + 2; ++e) {
+                    float ex = 0.f;
+#pragma unroll
+                    for (int d = 0; d < KGEN_DMAX; ++d) {
+                        const float df = kzs[p][d] - kgxs[e][d];
+                        ex = __builtin_fmaf(df, df, ex);
+                    }
+                    kval[p].v[e] = kgos * t_fexp(-0.5f * ex);
+                }
+                if (half == 1) rb[p] = kval[p];
+            }
+        }
     };
     // one four-element piece of the staged tile -> LDS (k-major images As[k][m], Bs[k][n])
     constexpr int NPIECE = PA + PB;
@@ -418,6 +469,10 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || N
 #pragma unroll
                 for (int j = 0; j < TN; ++j) bf[nxt][j] = bs[(ks + 1) * KS * LDB + j * MT];
             }
+            if constexpr (MIX == 2) {
+                static_assert(MIX != 2 || KS0 >= 2, "generated operand: two k-steps ahead of the staging stores");
+                if (ks < 2 && stage) kgen_half(rb, ks);
+            }
             if (ks >= KS0 && stage) {
 #pragma unroll
                 for (int q = (ks - KS0) * PPS; q < (ks - KS0 + 1) * PPS && q < NPIECE; ++q) store_piece(buf ^ 1, q, ra, rb, masked_c, set);
@@ -480,7 +535,17 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || N
             Frag4<TB> rsb[DEEP][PB];
             auto issue = [&](int t, int set) __attribute__((always_inline)) {
                 la.load_fast(rsa[set], (int64_t)t * BK);
-                lb.load_fast(rsb[set], (int64_t)t * BK);
+                if constexpr (MIX == 2) {
+                    // rows of z for this thread's pieces (one k each), parked in the staging registers of B
+#pragma unroll
+                    for (int p = 0; p < PB; ++p) {
+                        const int64_t k = kbeg + (int64_t)t * BK + lb.pk(p);
+#pragma unroll
+                        for (int d = 0; d < KGEN_DMAX; ++d) rsb[set][p].v[d] = d < kgD ? kgz[k * kgD + d] : 0.f;
+                    }
+                } else {
+                    lb.load_fast(rsb[set], (int64_t)t * BK);
+                }
                 const int64_t k0 = kbeg + (int64_t)t * BK;
                 st_adiag[set] = (aL || aU) && (k0 < m0 + BM) && (k0 + BK > m0);
                 st_bdiag[set] = (bL || bU) && (k0 < n0 + BN) && (k0 + BK > n0);
@@ -491,6 +556,8 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || N
 #pragma unroll
             for (int d = 1; d < DEEP; ++d)
                 if (d < nt) issue(d, d);
+            kgen_half(rsb[0], 0);
+            kgen_half(rsb[0], 1);
             sstore(0, rsa[0], rsb[0], 0);
             __syncthreads();
             for (int tb = 0; tb < nt; tb += DEEP) {
@@ -1005,9 +1072,16 @@ namespace {
 // A = L^-1-style projection with float64 arithmetic on float32 data (gemm_kernel<double, 128, 64, 16, ..., MIX = 1>):
 // Y[b] = W[b] X[b] (W: float64 lower triangular (M x M); X, Y: float32 (M x n)), plus the column-statistic partials of
 // nsgp_svgp_tri_gemm_colstats (float32; ceil(M / 128) tile rows).
+struct KzxGen { const float *z, *x, *ls, *os; int D; int64_t sx; };   // generated B operand (Epi::kz ...), or null
+
+static inline bool f64acc_whole(const double* W, int64_t M, int64_t n, int bm) {
+    return M % 4 == 0 && (uintptr_t)W % 32 == 0 && M % bm == 0 && n % NSGP_F64ACC_BN == 0 && M % NSGP_F64ACC_BK == 0;
+}
+
 int tri_gemm_colstats_f64acc_impl(const double* W, const float* X, const float* rowvec, int64_t batch, int64_t M, int64_t n,
-                                  float* Y, float* part_dot, float* part_sq, int64_t part_rows, void* stream) {
-    if (!W) return -1; if (!X) return -2; if (batch < 0) return -4; if (M < 0) return -5; if (n < 0) return -6;
+                                  float* Y, float* part_dot, float* part_sq, int64_t part_rows, void* stream,
+                                  const KzxGen* kg = nullptr) {
+    if (!W) return -1; if (!X && !kg) return -2; if (batch < 0) return -4; if (M < 0) return -5; if (n < 0) return -6;
     if (!Y) return -7; if (!part_sq) return -9;
     if (batch == 0 || M == 0 || n == 0) return 0;
     constexpr int BN_ = NSGP_F64ACC_BN, BK_ = NSGP_F64ACC_BK;
@@ -1026,27 +1100,34 @@ int tri_gemm_colstats_f64acc_impl(const double* W, const float* X, const float* 
     g.nbk = (int)batch; g.xcd_chunk = 0; g.xcd_group = 0; g.part_rows = (int)part_rows;
     g.modeA = 0; g.modeB = 1;
     g.vecA = (M % 4 == 0) && ((uintptr_t)W % 32 == 0);
-    g.vecB = (n % 4 == 0) && ((uintptr_t)X % 16 == 0);
+    g.vecB = kg ? 1 : ((n % 4 == 0) && ((uintptr_t)X % 16 == 0));
     if (g.tiles_m * g.tiles_n > 2147483647LL || batch > 65535) return -24;
     Epi ep{};
     ep.kind = 1; ep.rv = rowvec; ep.p0 = part_dot; ep.p1 = part_sq; ep.modeA = 0; ep.modeB = 1;
+    if (kg) {
+        if (!kg->z || !kg->x || !kg->ls || !kg->os) return -2;
+        if (kg->D < 1 || kg->D > KGEN_DMAX) return -3;
+        if (!f64acc_whole(W, M, n, BM_)) return -11;          // the generated operand exists for whole tiles only
+        ep.kz = kg->z; ep.kx = kg->x; ep.kls = kg->ls; ep.kos = kg->os; ep.kD = kg->D; ep.kx_sx = kg->sx;
+    }
     const bool whole = g.vecA && g.vecB && M % BM_ == 0 && n % BN_ == 0 && M % BK_ == 0;
     dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)batch, 1);
     hipStream_t st = (hipStream_t)stream;
     // the kernel takes its B / C pointers as double* and reinterprets them (MIX = 1)
     const double* Bp = reinterpret_cast<const double*>(X);
     double* Cp = reinterpret_cast<double*>(Y);
-    auto go = [&](auto bm_c, auto edge_c) {
-        constexpr int BMc = decltype(bm_c)::value, EDGEc = decltype(edge_c)::value;
+    auto go = [&](auto bm_c, auto edge_c, auto mix_c) {
+        constexpr int BMc = decltype(bm_c)::value, EDGEc = decltype(edge_c)::value, MIXc = decltype(mix_c)::value;
         constexpr size_t lds = 2 * BK_ * ((BMc + Mfma<double>::PAD) + (BN_ + Mfma<double>::PAD)) * sizeof(double);
-        nsgp_opt_in_lds((const void*)gemm_kernel<double, BMc, BN_, BK_, 0, 1, 1, 0, 0, EDGEc, 1>, lds);
-        hipLaunchKernelGGL((gemm_kernel<double, BMc, BN_, BK_, 0, 1, 1, 0, 0, EDGEc, 1>), grid, dim3(256), lds, st, g, 1.0, W,
-                           Bp, 0.0, Cp, (double*)nullptr, ep);
+        nsgp_opt_in_lds((const void*)gemm_kernel<double, BMc, BN_, BK_, 0, 1, 1, 0, 0, EDGEc, MIXc>, lds);
+        hipLaunchKernelGGL((gemm_kernel<double, BMc, BN_, BK_, 0, 1, 1, 0, 0, EDGEc, MIXc>), grid, dim3(256), lds, st, g, 1.0,
+                           W, Bp, 0.0, Cp, (double*)nullptr, ep);
     };
-    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
     using B64 = std::integral_constant<int, 64>; using B128 = std::integral_constant<int, 128>;
-    if (BM_ == 128) { if (whole) go(B128{}, I0{}); else go(B128{}, I1{}); }
-    else { if (whole) go(B64{}, I0{}); else go(B64{}, I1{}); }
+    if (kg) { if (BM_ == 128) go(B128{}, I0{}, I2{}); else go(B64{}, I0{}, I2{}); }
+    else if (BM_ == 128) { if (whole) go(B128{}, I0{}, I1{}); else go(B128{}, I1{}, I1{}); }
+    else { if (whole) go(B64{}, I0{}, I1{}); else go(B64{}, I1{}, I1{}); }
     return nsgp_launch_status();
 }
 }  // namespace
@@ -1054,6 +1135,16 @@ int tri_gemm_colstats_f64acc_impl(const double* W, const float* X, const float* 
 extern "C" {
 
 size_t nsgp_svgp_f64acc_tiles(int64_t M) { return M > 0 ? (size_t)cdiv64(M, 128) : 0; }
+int nsgp_svgp_kzx_gemm_colstats_f64acc(const double* W, const float* z, const float* x, int64_t sx, const float* ls,
+                                       const float* os, int D, const float* rowvec, int64_t batch, int64_t M, int64_t n,
+                                       float* Y, float* part_dot, float* part_sq, int64_t part_rows, void* stream) {
+    KzxGen kg{z, x, ls, os, D, sx};
+    return tri_gemm_colstats_f64acc_impl(W, nullptr, rowvec, batch, M, n, Y, part_dot, part_sq, part_rows, stream, &kg);
+}
+int nsgp_svgp_kzx_gemm_supported(const double* W, int64_t M, int64_t n, int64_t batch, int D) {
+    return (D >= 1 && D <= KGEN_DMAX && M > 0 && n > 0 && batch > 0 &&
+            f64acc_whole(W, M, n, f64acc_tile_rows(M, n, batch))) ? 1 : 0;
+}
 size_t nsgp_svgp_f64acc_tiles_for(int64_t M, int64_t n, int64_t batch) {
     return (M > 0 && n > 0 && batch > 0) ? (size_t)cdiv64(M, f64acc_tile_rows(M, n, batch)) : 0;
 }

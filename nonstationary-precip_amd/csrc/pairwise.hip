@@ -130,7 +130,7 @@ template <typename T, int D> struct RbfOp {
 #pragma unroll
         for (int d = 0; d < DM; ++d) {
             const T df = r.x[d] - c.x[d];
-            ex += df * df;
+            ex = t_fma(df, df, ex);                  // explicit: gemm.hip's generated-Kzx loader repeats this sum bit for bit
         }
         return t_fexp(T(-0.5) * ex);
     }

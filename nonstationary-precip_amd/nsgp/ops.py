@@ -487,21 +487,46 @@ def _affine_args(affine, batch, n, ref):
     return x, sxb, D, w, swb, c, scb
 
 
-def svgp_project(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None):
+def svgp_kzx_fusable(W64f, Z, x, n):
+    """True when A = W Kzx can run with Kzx generated inside the GEMM loader (nsgp_svgp_kzx_gemm_colstats_f64acc):
+    float32 layer with its float64 W, D <= 4, whole tiles."""
+    if W64f is None or W64f.dtype != torch.float64 or Z.dtype != torch.float32 or not W64f.is_contiguous():
+        return False
+    batch, M, D = Z.shape
+    return bool(_lib.load().nsgp_svgp_kzx_gemm_supported(_p(W64f), M, n, batch, D))
+
+
+def svgp_project(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None, kernel_inputs=None):
     """Fused K6 forward: A = W Kzx, C = Lq^T A (triangular MFMA GEMMs) with the column statistics reduced in
     the GEMM epilogues.  W, Lq:(b,M,M) lower; Kzx:(b,M,n); m:(b,M); base:(b,).
     Returns A, C, mean = A^T m (+ the affine prior mean x w + c, `affine` = (x, w, c)), var = base + base_add +
     colsum(C^2 - A^2).
     W64f: the float64 W of a float32 layer -- A is then accumulated in float64 on the float32 Kzx and rounded once
-    (nsgp_svgp_tri_gemm_colstats_f64acc: the reference's float64 solve); W itself (float32) is only used by the backward."""
-    ref = _chk(W, Kzx, Lq, m, base)
-    W, Kzx, Lq, m, base = _c(W), _c(Kzx), _c(Lq), _c(m), _c(base.reshape(-1))
-    batch, M, n = Kzx.shape
+    (nsgp_svgp_tri_gemm_colstats_f64acc: the reference's float64 solve); W itself (float32) is only used by the backward.
+    kernel_inputs=(Z, x, ls, os) with Kzx=None (and W64f, `svgp_kzx_fusable`): Kzx is never materialised, its tiles are
+    generated inside the loader of the first product from Z:(b,M,D), x:(n,D) or (b,n,D), ls:(b,D), os:(b,)."""
+    fused = Kzx is None
+    if fused:
+        if kernel_inputs is None or W64f is None:
+            raise BackendError('svgp_project: Kzx=None needs kernel_inputs and W64f')
+        kZ, kx, kls, kos = kernel_inputs
+        ref = _chk(W, Lq, m, base, kZ, kx, kls, kos)
+        kZ, kx, kls, kos = _c(kZ), _c(kx), _c(kls), _c(kos.reshape(-1))
+        W, Lq, m, base = _c(W), _c(Lq), _c(m), _c(base.reshape(-1))
+        batch, M, D = kZ.shape
+        n = kx.shape[-2]
+        if kx.shape[-1] != D or (kx.dim() == 3 and kx.shape[0] != batch) or kls.shape != (batch, D) or kos.shape != (batch,):
+            raise BackendError('svgp_project: kernel_inputs shapes')
+    else:
+        ref = _chk(W, Kzx, Lq, m, base)
+        W, Kzx, Lq, m, base = _c(W), _c(Kzx), _c(Lq), _c(m), _c(base.reshape(-1))
+        batch, M, n = Kzx.shape
     if W.shape != (batch, M, M) or Lq.shape != (batch, M, M) or m.shape != (batch, M) or base.shape != (batch,):
         raise BackendError('svgp_project: shapes')
     lib = _lib.load()
     T = int(lib.nsgp_svgp_colstats_tiles(M, n, batch, ref.element_size()))
-    A, C = torch.empty_like(Kzx), torch.empty_like(Kzx)
+    A = torch.empty((batch, M, n), dtype=ref.dtype, device=ref.device)
+    C = torch.empty_like(A)
     sfx, st = _sfx(ref), _stream()
     flops = 1.0 * M * M * n * batch                      # 2 M M n / 2 (triangular operand)
     if W64f is not None:
@@ -513,8 +538,13 @@ def svgp_project(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None):
         T32, T = T, max(T, T64)
         # tile rows one of the two kernels does not fill (their tile heights differ for some shapes) stay zero
         part = (torch.zeros if T64 != T32 else torch.empty)((3, batch, max(T, 1), n), dtype=ref.dtype, device=ref.device)
-        _timed(lambda: _lib.call('nsgp_svgp_tri_gemm_colstats_f64acc', _p(W64f), _p(Kzx), _p(m), batch, M, n, _p(A),
-                                 _p(part[0]), _p(part[1]), T, st), flops, 'f64acc')
+        if fused:
+            _timed(lambda: _lib.call('nsgp_svgp_kzx_gemm_colstats_f64acc', _p(W64f), _p(kZ), _p(kx),
+                                     n * D if kx.dim() == 3 else 0, _p(kls), _p(kos), D, _p(m), batch, M, n, _p(A),
+                                     _p(part[0]), _p(part[1]), T, st), flops, 'f64acc')
+        else:
+            _timed(lambda: _lib.call('nsgp_svgp_tri_gemm_colstats_f64acc', _p(W64f), _p(Kzx), _p(m), batch, M, n, _p(A),
+                                     _p(part[0]), _p(part[1]), T, st), flops, 'f64acc')
     else:
         part = torch.empty((3, batch, max(T, 1), n), dtype=ref.dtype, device=ref.device)
         _timed(lambda: _lib.call(f'nsgp_svgp_tri_gemm_colstats_{sfx}', _p(W), 0, _p(Kzx), _p(m), batch, M, n, _p(A),

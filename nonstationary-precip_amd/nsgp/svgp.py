@@ -177,15 +177,20 @@ class SVGPLayerFn(torch.autograd.Function):
         from .gp import settings
         if x.dtype != torch.float32 or not (settings.whiten_matmul_f64.on() or settings.forward_precision.value() == 'bf16_all'):
             W64f = None
-        Kzx = ops.rbf_build(Z, x, ls, os_)                                       # (b,M,n)  (the backward needs it in float32)
         affine = None if (mean_w is None and mean_c is None) else (x, mean_w, mean_c)
         fp = settings.forward_precision.value()
+        # Kzx never materialised in the forward pass: its tiles are generated inside the loader of A = W Kzx (float32 layers
+        # with the float64-accumulating product, whole tiles); the backward builds it once for Wbar = tril(Abar Kzx^T)
+        fuse = fp == 'f32' and settings.fuse_kzx.on() and W64f is not None and \
+            ops.svgp_kzx_fusable(W64f, Z, x, x.shape[-2])
+        Kzx = None if fuse else ops.rbf_build(Z, x, ls, os_)                     # (b,M,n)
         if x.dtype == torch.float32 and fp in ('bf16', 'bf16_all') and Z.shape[-2] % 8 == 0:
             # BASELINE configs[4]'s "bf16 forward": C = Lq^T A on the bf16 matrix cores; 'bf16_all' also A = W Kzx
             A, C, mean, var = ops.svgp_project_bf16(W, Kzx, Lq, m, os_, base_add=VAR_JITTER, affine=affine, W64f=W64f,
                                                     kernel_inputs=(Z, x, ls, os_) if fp == 'bf16_all' else None)
         else:
-            A, C, mean, var = ops.svgp_project(W, Kzx, Lq, m, os_, base_add=VAR_JITTER, affine=affine, W64f=W64f)   # 2 GEMMs
+            A, C, mean, var = ops.svgp_project(W, Kzx, Lq, m, os_, base_add=VAR_JITTER, affine=affine, W64f=W64f,
+                                               kernel_inputs=(Z, x, ls, os_) if fuse else None)      # 2 GEMMs
         ctx.save_for_backward(x, Z, ls, os_, m, Lq, W, Kzx, A, C, mean_w, mean_c)
         ctx.w_dtype = W64.dtype
         return mean, var
@@ -193,6 +198,8 @@ class SVGPLayerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gmean, gvar):
         x, Z, ls, os_, m, Lq, W, Kzx, A, C, mean_w, mean_c = ctx.saved_tensors
+        if Kzx is None:                                  # fused forward: built here, once, for the Wbar product
+            Kzx = ops.rbf_build(Z, x, ls, os_)
         gmean = gmean.contiguous()
         affine = None if (mean_w is None and mean_c is None) else (x, mean_w, mean_c)
         Abar, Lqbar, mbar, basebar, wbar, cbar = ops.svgp_project_bwd(Lq, m, A, C, gmean, gvar.contiguous(),

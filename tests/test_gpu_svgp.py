@@ -208,3 +208,58 @@ def test_non_positive_definite_kzz_is_reported_when_asked():
             whiten([(Z, ls, -os_)], jitter=0.0)
         Ws, info = whiten([(Z, ls, os_)], jitter=1e-4)       # duplicate points: the default jitter repairs them
         assert int(info[0]) == 0
+
+
+@pytest.mark.parametrize('M,n,batch,D,shared_x', [(256, 512, 2, 3, True), (1024, 4096, 1, 2, True), (128, 128, 3, 4, False),
+                                                   (1024, 640, 2, 1, True)])
+def test_projection_with_generated_kzx_equals_the_materialised_one(M, n, batch, D, shared_x):
+    """nsgp_svgp_kzx_gemm_colstats_f64acc generates the Kzx tiles inside the loader of A = W Kzx with the arithmetic of the
+    RBF build kernel: A, C and the column statistics must equal the materialised path bit for bit (128- and 64-row tile
+    variants, shared and per-GP inputs, D = 1..4); shapes outside the whole-tile contract are refused by the query."""
+    from nsgp import ops
+    g = torch.Generator().manual_seed(M + n)
+    Z = torch.randn(batch, M, D, generator=g).cuda()
+    x = (1.3 * torch.randn(*( (n, D) if shared_x else (batch, n, D)), generator=g)).cuda()
+    ls = (0.6 + torch.rand(batch, D, generator=g)).cuda()
+    os_ = (0.5 + torch.rand(batch, generator=g)).cuda()
+    W64 = torch.tril(torch.randn(batch, M, M, generator=g, dtype=torch.float64) / M ** 0.5).cuda()
+    W = W64.float()
+    Lq = torch.tril(torch.randn(batch, M, M, generator=g) / M ** 0.5).cuda()
+    m = torch.randn(batch, M, generator=g).cuda()
+    assert ops.svgp_kzx_fusable(W64, Z, x, n)
+    Kzx = ops.rbf_build(Z, x, ls, os_)
+    ref = ops.svgp_project(W, Kzx, Lq, m, os_, base_add=1e-4, W64f=W64)
+    got = ops.svgp_project(W, None, Lq, m, os_, base_add=1e-4, W64f=W64, kernel_inputs=(Z, x, ls, os_))
+    for a, b, name in zip(ref, got, ('A', 'C', 'mean', 'var')):
+        assert torch.equal(a, b), (name, float((a - b).abs().max()))
+    # not whole tiles / too many input dimensions: the caller keeps the materialised path
+    assert not ops.svgp_kzx_fusable(W64[:, :M - 4, :M - 4].contiguous(), Z[:, :M - 4].contiguous(), x, n)
+    assert not ops.svgp_kzx_fusable(W64, Z, x, n - 4)
+    assert not ops.svgp_kzx_fusable(W64, torch.randn(batch, M, 5).cuda(), x, n)
+
+
+def test_layer_with_generated_kzx_matches_the_materialised_layer():
+    """settings.fuse_kzx: the SVGP layer's outputs and every gradient are those of the default (materialised) data flow,
+    bit for bit -- the forward values are identical and the backward runs the same launches on a Kzx built there."""
+    from nsgp import ops
+    from nsgp.gp import settings
+    from nsgp.svgp import svgp_marginal
+    g = torch.Generator().manual_seed(77)
+    b, M, n, D = 2, 256, 512, 3
+    x = torch.randn(n, D, generator=g).cuda().requires_grad_()
+    Z = torch.randn(b, M, D, generator=g).cuda().requires_grad_()
+    ls = (0.8 + torch.rand(b, D, generator=g)).cuda().requires_grad_()
+    os_ = (0.7 + torch.rand(b, generator=g)).cuda().requires_grad_()
+    m = (0.3 * torch.randn(b, M, generator=g)).cuda().requires_grad_()
+    Lq = (torch.eye(M) + 0.05 * torch.tril(torch.randn(b, M, M, generator=g))).cuda().requires_grad_()
+    gm, gv = torch.randn(b, n, generator=g).cuda(), torch.randn(b, n, generator=g).cuda()
+    outs = []
+    for fuse in (False, True):
+        for t in (x, Z, ls, os_, m, Lq):
+            t.grad = None
+        with settings.fuse_kzx(fuse):
+            mean, var, _ = svgp_marginal(x, Z, ls, os_, m, Lq)
+            ((mean * gm).sum() + (var * gv).sum()).backward()
+        outs.append([mean.detach().clone(), var.detach().clone()] + [t.grad.clone() for t in (x, Z, ls, os_, m, Lq)])
+    for a, c in zip(*outs):
+        assert torch.equal(a, c)
