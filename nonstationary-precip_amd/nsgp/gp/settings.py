@@ -164,8 +164,8 @@ class fuse_kzx(_feature_flag):
     """On: a float32 SVGP layer's forward projection A = W Kzx generates the Kzx tiles inside the GEMM loader
     (nsgp_svgp_kzx_gemm_colstats_f64acc) instead of reading a materialised Kzx -- same values bit for bit, one (M x n)
     matrix less through HBM per layer and step (the backward still builds it once for Wbar = tril(Abar Kzx^T)).
-    Off (default): Kzx is built by the RBF kernel first.  Measured at the headline shape: the float64 matrix instruction
-    shares the SIMD's float64 data path with the vector ALU, so the ~60 VALU instructions per K-tile of the generator
-    come straight out of the product's MFMA rate (1.08 -> 1.23 ms per step) while the (M x n) round trip it saves was
-    never the bound: 5.10 ms/step with this off, 5.28 with it on.  Kept as a memory-saving mode (168 MB at n = 40960)."""
+    Off (default): Kzx is built by the RBF kernel first.  Measured at the headline shape: the generator (a row of z per
+    K-tile through scalar loads, a division per coordinate, four exp) slows the product from 1.08 to 1.23 ms per step,
+    while the (M x n) round trip it saves was never the bound: 5.10 ms/step with this off, 5.28 with it on.  Kept as a
+    memory-saving mode (168 MB at n = 40960)."""
     _state = False
