@@ -127,6 +127,8 @@ int nsgp_ps2d_build_bwd_f64(const double* x1, const double* x2, const double* si
 #define NSGP_GEMM_C_LOWER  16   /* only the lower triangle (n <= m) of C is computed/stored; the
                                    strict upper triangle is written as zero when beta == 0 */
 #define NSGP_GEMM_NO_SPLITK 32  /* never split the inner dimension (no workspace needed) */
+#define NSGP_GEMM_C_HALFDIAG 128 /* the diagonal of alpha*op(A)*op(B) is halved before beta*C is added (Phi of the
+                                   Cholesky backward: tril with halved diagonal, without a pass of its own) */
 #define NSGP_GEMM_C_NOFILL  64  /* with C_LOWER: leave the strict upper triangle of C untouched (the consumer reads C
                                    through a LOWER operand flag, which never loads it) -- no memset nodes */
 size_t nsgp_gemm_workspace(int64_t M, int64_t N, int64_t K, int64_t nb1, int64_t nb2, int elem_size, int flags);
@@ -188,6 +190,14 @@ int nsgp_potrf_f32(float* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, 
 int nsgp_potrf_f64(double* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int32_t* info,
                    void* ws, size_t ws_bytes, void* stream);
 size_t nsgp_trtri_workspace(int64_t n, int64_t batch, int elem_size);
+/* X = chol(A)^-1 in one call (the DSVI whitening chain needs only the inverse): the factor's write-back pass is skipped, so
+ * on return A holds intermediate data (strictly lower part = L's, diagonal blocks and upper triangle undefined) and X the
+ * lower-triangular inverse.  Replaces psd_safe_cholesky + triangular_solve(eye) of gpytorch's VariationalStrategy (SURVEY
+ * A.3) behind /root/reference/models/dgps.py:29-33.  ws: nsgp_potrf_workspace(n, batch) + nsgp_trtri_workspace(n, batch). */
+int nsgp_potrf_trtri_f32(float* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int32_t* info, float* X,
+                         int64_t ldx, int64_t sX, void* ws, size_t ws_bytes, void* stream);
+int nsgp_potrf_trtri_f64(double* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int32_t* info, double* X,
+                         int64_t ldx, int64_t sX, void* ws, size_t ws_bytes, void* stream);
 int nsgp_trtri_f32(const float* L, int64_t n, int64_t ldl, int64_t sL, float* X, int64_t ldx,
                    int64_t sX, int64_t batch, void* ws, size_t ws_bytes, void* stream);
 int nsgp_trtri_f64(const double* L, int64_t n, int64_t ldl, int64_t sL, double* X, int64_t ldx,

@@ -782,6 +782,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || N
                             if (beta == T(0)) out[row * ldo + col] = T(0);
                         } else {
                             v *= alpha;
+                            if ((g.flags & NSGP_GEMM_C_HALFDIAG) && row == col) v *= T(0.5);
                             if (beta != T(0)) v += beta * out[row * ldo + col];
                             out[row * ldo + col] = v;
                         }
@@ -809,6 +810,7 @@ __global__ void splitk_reduce_kernel(GemmArgs g, T alpha, const T* __restrict__ 
     T s = T(0);
     for (int64_t k = 0; k < g.ksplit; ++k) s += slabs[k * g.slab + idx];
     s *= alpha;
+    if ((g.flags & NSGP_GEMM_C_HALFDIAG) && row == col) s *= T(0.5);
     if (beta != T(0)) s += beta * *c;
     *c = s;
 }
@@ -950,7 +952,7 @@ int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam,
     if (epi) ep = *epi;
     if (tiles_m_out) *tiles_m_out = g.tiles_m;
     const int ekind = ep.kind, eks = ep.ks != nullptr;
-    if (ekind != 0 && (g.ksplit != 1 || beta != T(0) || (flags & NSGP_GEMM_C_LOWER))) return -30;
+    if (ekind != 0 && (g.ksplit != 1 || beta != T(0) || (flags & (NSGP_GEMM_C_LOWER | NSGP_GEMM_C_HALFDIAG)))) return -30;
     const int64_t bnn = p.narrow ? 64 : bmn, bkk = (bmn == 128 ? 32 : ((sizeof(T) == 8 && ekind == 0 && !eks) ? NSGP_F64_BK : 16));
     // whole, vector-loadable tiles everywhere -> the variant without bounds code (EDGE = 0)
     const bool whole = g.vecA && g.vecB && M % bmn == 0 && N % bnn == 0 && K % bkk == 0 && g.kper % bkk == 0;

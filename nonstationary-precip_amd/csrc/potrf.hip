@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256) void potrf_finalize_kernel(T* __restrict__ A, 
 
 template <typename T>
 int potrf_impl(T* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int32_t* info, void* ws, size_t wsb,
-               void* stream) {
+               void* stream, bool finalize = true) {
     if (n < 0) return -2; if (lda < n) return -3; if (batch < 0) return -5;
     if (n == 0 || batch == 0) return 0;
     if (!A) return -1; if (!info) return -6;
@@ -562,8 +562,10 @@ int potrf_impl(T* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int32_t*
             if (rc) return rc;
         }
     }
-    hipLaunchKernelGGL((potrf_finalize_kernel<T>), dim3((unsigned)npanels, (unsigned)npanels, (unsigned)batch),
-                       dim3(256), 0, st, A, n, lda, sA, (const T*)wsL, npanels);
+    // finalize = false (nsgp_potrf_trtri): the diagonal blocks stay in the side buffer, where the inverse reads them
+    if (finalize)
+        hipLaunchKernelGGL((potrf_finalize_kernel<T>), dim3((unsigned)npanels, (unsigned)npanels, (unsigned)batch),
+                           dim3(256), 0, st, A, n, lda, sA, (const T*)wsL, npanels);
     return nsgp_launch_status();
 }
 
@@ -583,7 +585,10 @@ __device__ __forceinline__ typename Mma16<T>::acc_t mm16(const T* A, int lda, co
 // with the identity.  Everything right of the block in its rows is zeroed (X is lower triangular).
 template <typename T>
 __global__ __launch_bounds__(256) void trtri_diag_kernel(const T* __restrict__ L, int64_t n, int64_t ldl, int64_t sL,
-                                                         T* __restrict__ X, int64_t ldx, int64_t sX) {
+                                                         T* __restrict__ X, int64_t ldx, int64_t sX,
+                                                         const T* __restrict__ Dsrc) {
+    // Dsrc != null: the diagonal blocks come from potrf's side buffer (batch, panels, 64, 64) -- L's own diagonal blocks
+    // have not been written back (nsgp_potrf_trtri skips that pass)
     typedef Mma16<T> MM;
     typedef typename MM::acc_t acc_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char panel_smem[];
@@ -602,7 +607,8 @@ __global__ __launch_bounds__(256) void trtri_diag_kernel(const T* __restrict__ L
 #pragma unroll
         for (int i = 0; i < SB; ++i) {
             const int64_t rr = r0 + w * SB + i, cc = r0 + lane;
-            lr[i] = Lb[(rr < n ? rr : n - 1) * ldl + (cc < n ? cc : n - 1)];
+            lr[i] = Dsrc ? Dsrc[((b * gridDim.x + blockIdx.x) * NB + (w * SB + i)) * NB + lane]
+                         : Lb[(rr < n ? rr : n - 1) * ldl + (cc < n ? cc : n - 1)];
         }
 #pragma unroll
         for (int i = 0; i < SB; ++i) keep(lr[i]);
@@ -672,7 +678,7 @@ __global__ __launch_bounds__(256) void trtri_diag_kernel(const T* __restrict__ L
 
 template <typename T>
 int trtri_impl(const T* L, int64_t n, int64_t ldl, int64_t sL, T* X, int64_t ldx, int64_t sX, int64_t batch,
-               void* ws, size_t wsb, void* stream) {
+               void* ws, size_t wsb, void* stream, const T* diag_src = nullptr) {
     if (n < 0) return -2; if (ldl < n) return -3; if (ldx < n) return -6; if (batch < 0) return -8;
     if (n == 0 || batch == 0) return 0;
     if (!L) return -1; if (!X) return -5;
@@ -683,7 +689,7 @@ int trtri_impl(const T* L, int64_t n, int64_t ldl, int64_t sL, T* X, int64_t ldx
     const size_t diag_lds = (3 * (size_t)NB * LDD + 4 * SB * LDI + NB) * sizeof(T);
     nsgp_opt_in_lds((const void*)trtri_diag_kernel<T>, diag_lds);
     hipLaunchKernelGGL((trtri_diag_kernel<T>), dim3((unsigned)cdiv64(n, NB), (unsigned)batch), dim3(256), diag_lds, st,
-                       L, n, ldl, sL, X, ldx, sX);
+                       L, n, ldl, sL, X, ldx, sX, diag_src);
     T* Tm = (T*)ws;                      // (batch, n, n) scratch, same indexing as X with ld = n
     for (int64_t s = NB; s < n; s *= 2) {
         // pairs (A = X[i0:i0+s, i0:i0+s], B = X[i0+s:i0+s+h, ...], C = L[i0+s:i0+s+h, i0:i0+s])
@@ -716,6 +722,23 @@ int trtri_impl(const T* L, int64_t n, int64_t ldl, int64_t sL, T* X, int64_t ldx
     return nsgp_launch_status();
 }
 
+// Cholesky factor and its inverse in one call: X = chol(A)^-1 (lower), A is overwritten with intermediate data (its strictly
+// lower part holds L21; the diagonal blocks and the upper triangle are NOT a valid factor).  Saves the write-back pass of
+// the factor (potrf_finalize_kernel: one launch, 2 n^2 elements of traffic) on the DSVI whitening chain, which only needs
+// the inverse.  ws: nsgp_potrf_workspace + nsgp_trtri_workspace bytes.
+template <typename T>
+int potrf_trtri_impl(T* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int32_t* info, T* X, int64_t ldx, int64_t sX,
+                     void* ws, size_t wsb, void* stream) {
+    if (n < 0) return -2; if (batch < 0) return -5;
+    if (n == 0 || batch == 0) return 0;
+    const size_t w1 = (size_t)batch * cdiv64(n, NB) * NB * NB * sizeof(T);
+    const size_t w2 = n > NB ? (size_t)batch * n * n * sizeof(T) : 0;
+    if (!ws || wsb < w1 + w2) return -11;
+    int rc = potrf_impl<T>(A, n, lda, sA, batch, info, ws, w1, stream, false);
+    if (rc) return rc;
+    return trtri_impl<T>(A, n, lda, sA, X, ldx, sX, batch, (char*)ws + w1, w2, stream, (const T*)ws);
+}
+
 }  // namespace
 
 extern "C" {
@@ -735,6 +758,14 @@ int nsgp_potrf_f64(double* A, int64_t n, int64_t lda, int64_t sA, int64_t batch,
 size_t nsgp_trtri_workspace(int64_t n, int64_t batch, int elem_size) {
     if (n <= NB || batch <= 0) return 0;
     return (size_t)batch * n * n * elem_size;
+}
+int nsgp_potrf_trtri_f32(float* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int32_t* info, float* X,
+                         int64_t ldx, int64_t sX, void* ws, size_t wsb, void* stream) {
+    return potrf_trtri_impl<float>(A, n, lda, sA, batch, info, X, ldx, sX, ws, wsb, stream);
+}
+int nsgp_potrf_trtri_f64(double* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int32_t* info, double* X,
+                         int64_t ldx, int64_t sX, void* ws, size_t wsb, void* stream) {
+    return potrf_trtri_impl<double>(A, n, lda, sA, batch, info, X, ldx, sX, ws, wsb, stream);
 }
 int nsgp_trtri_f32(const float* L, int64_t n, int64_t ldl, int64_t sL, float* X, int64_t ldx, int64_t sX,
                    int64_t batch, void* ws, size_t wsb, void* stream) {

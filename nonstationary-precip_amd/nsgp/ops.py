@@ -16,6 +16,7 @@ from . import _lib
 from ._lib import BackendError
 
 GEMM_A_LOWER, GEMM_A_UPPER, GEMM_B_LOWER, GEMM_B_UPPER, GEMM_C_LOWER, GEMM_NO_SPLITK, GEMM_C_NOFILL = 1, 2, 4, 8, 16, 32, 64
+GEMM_C_HALFDIAG = 128
 
 
 # --------------------------------------------------------------------------------------------
@@ -390,6 +391,24 @@ def trtri(L):
     ws = _ws(lib.nsgp_trtri_workspace(n, batch, ref.element_size()), ref.device)
     _lib.call(f'nsgp_trtri_{_sfx(ref)}', _p(L), n, n, n * n, _p(X), n, n * n, batch, _p(ws), ws.numel(), _stream())
     return X
+
+
+def potrf_trtri_(A):
+    """(X, info) with X = chol(A)^-1 (lower triangular) for a contiguous (batched) SPD matrix that is CONSUMED: on return A
+    holds intermediate data, not a factor.  One chain of launches without the factor's write-back pass."""
+    ref = _chk(A)
+    if A.dim() not in (2, 3) or A.shape[-1] != A.shape[-2] or not A.is_contiguous():
+        raise BackendError('potrf_trtri_: contiguous square (batched) matrix expected')
+    n = A.shape[-1]
+    batch = A.shape[0] if A.dim() == 3 else 1
+    X = torch.empty_like(A)
+    info = (torch.empty if n > 0 else torch.zeros)(batch, dtype=torch.int32, device=ref.device)
+    lib = _lib.load()
+    ws = _ws(lib.nsgp_potrf_workspace(n, batch, ref.element_size()) + lib.nsgp_trtri_workspace(n, batch, ref.element_size()),
+             ref.device)
+    _lib.call(f'nsgp_potrf_trtri_{_sfx(ref)}', _p(A), n, n, n * n, batch, _p(info), _p(X), n, n * n, _p(ws), ws.numel(),
+              _stream())
+    return X, info
 
 
 def chol_bwd_phi_sym(P):

@@ -19,7 +19,7 @@ folded into a GEMM epilogue and an operand loader) + one batched M^3 Cholesky ad
 import torch
 
 from . import ops
-from .ops import GEMM_A_LOWER, GEMM_A_UPPER, GEMM_B_LOWER, GEMM_B_UPPER, GEMM_C_LOWER, GEMM_C_NOFILL
+from .ops import GEMM_A_LOWER, GEMM_A_UPPER, GEMM_B_LOWER, GEMM_B_UPPER, GEMM_C_LOWER, GEMM_C_NOFILL, GEMM_C_HALFDIAG
 
 VAR_JITTER = 1e-4          # data_data_covar.add_jitter(1e-4) in VariationalStrategy.forward
 
@@ -55,8 +55,7 @@ class WhitenFn(torch.autograd.Function):
             z64.append((Zd, lsd, osd))
             ops.rbf_build(Zd, Zd, lsd, osd, diag_add=jitter, out=K[off:off + Z.shape[0]])
             off += Z.shape[0]
-        L, info = ops.potrf(K, overwrite=True)
-        W64 = ops.trtri(L)
+        W64, info = ops.potrf_trtri_(K)          # K is consumed; the factor itself is never needed
         ctx.save_for_backward(W64, *[t for g in z64 for t in g])
         ctx.sizes = [g[0].shape[0] for g in groups]
         ctx.dtypes = [g[0].dtype for g in groups]
@@ -102,8 +101,7 @@ class WhitenFn(torch.autograd.Function):
         # Kbar (G + G^T = 2 Kbar): every product keeps its triangular structure -- lower triangle of a lower x upper
         # product, lower x lower (lower result), upper x lower -- 2/3 of a dense M^3 product in total instead of 4/3.
         # The strict upper triangles of Phi and Phi W are never written and never read (LOWER operand flags mask them).
-        Phi = ops.gemm(Wb, Wc, tb=True, flags=GEMM_A_LOWER | GEMM_B_UPPER | GEMM_C_LOWER | GEMM_C_NOFILL)
-        ops.scale_diag_(Phi, 0.5)
+        Phi = ops.gemm(Wb, Wc, tb=True, flags=GEMM_A_LOWER | GEMM_B_UPPER | GEMM_C_LOWER | GEMM_C_NOFILL | GEMM_C_HALFDIAG)
         T = ops.gemm(Phi, Wc, flags=GEMM_A_LOWER | GEMM_B_LOWER | GEMM_C_LOWER | GEMM_C_NOFILL)
         Kbar = ops.gemm(Wc, T, ta=True, alpha=-1.0, flags=GEMM_A_UPPER | GEMM_B_LOWER)
         grads, off = [None, None], 0

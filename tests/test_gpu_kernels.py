@@ -287,6 +287,9 @@ def test_gemm_combined_triangular_flags_of_the_cholesky_adjoint(ops, dt, n, batc
     ops.scale_diag_(Phi, 0.5)
     Phi_ref = torch.tril(ref) - 0.5 * torch.diag_embed(torch.diagonal(ref, dim1=-2, dim2=-1))
     assert torch.allclose(torch.tril(Phi.cpu().double()), Phi_ref, **tol)
+    # the same Phi in one launch: the product's epilogue (or its split-K reduce) halves the diagonal
+    Phi1 = ops.gemm(Wb_in, W_in, tb=True, flags=ops.GEMM_A_LOWER | ops.GEMM_B_UPPER | fl | ops.GEMM_C_HALFDIAG)
+    assert torch.equal(torch.tril(Phi1), torch.tril(Phi))
     Phi_in = torch.tril(Phi) + junk.cuda()
     T = ops.gemm(Phi_in, W_in, flags=ops.GEMM_A_LOWER | ops.GEMM_B_LOWER | fl)
     T_ref = Phi_ref @ Wl
@@ -638,3 +641,23 @@ def test_gemm_narrow_tiles_for_single_round_triangular_launches(ops, N, ta, flag
     out = ops.gemm(Ain.cuda(), B.cuda(), ta=ta, flags=getattr(ops, 'GEMM_' + flag))
     err = float((out.cpu().double() - ref).abs().max()) / float(ref.abs().max())
     assert err < 2e-6, err
+
+
+
+@pytest.mark.parametrize('dt', [F32, F64])
+@pytest.mark.parametrize('n,batch', [(64, 1), (200, 2), (1024, 3), (1100, 1)])
+def test_potrf_trtri_fused_equals_potrf_then_trtri(ops, dt, n, batch):
+    """nsgp_potrf_trtri (the whitening chain's entry: no write-back of the factor) == potrf followed by trtri, bit for bit
+    on the lower triangle; info is reported as by potrf (LAPACK convention), including a failing leading minor."""
+    g = _g(60 + n)
+    A = torch.randn(batch, n, n, generator=g, dtype=torch.float64)
+    K = (A @ A.transpose(-1, -2) / n + torch.eye(n, dtype=torch.float64)).to(dt).cuda()
+    L, info0 = ops.potrf(K)
+    X0 = ops.trtri(L)
+    X1, info1 = ops.potrf_trtri_(K.clone())
+    assert info0.tolist() == [0] * batch and info1.tolist() == [0] * batch
+    assert torch.equal(torch.tril(X1), torch.tril(X0))
+    bad = K.clone()
+    bad[0, 5, 5] = -1.0
+    _, info2 = ops.potrf_trtri_(bad)
+    assert int(info2[0]) == 6
