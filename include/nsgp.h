@@ -311,6 +311,12 @@ int nsgp_svgp_lqbar_f32(const float* A, const float* C, const float* gvar, int64
                         float* Lqbar, void* ws, size_t ws_bytes, void* stream);
 int nsgp_svgp_lqbar_f64(const double* A, const double* C, const double* gvar, int64_t batch, int64_t M, int64_t n,
                         double* Lqbar, void* ws, size_t ws_bytes, void* stream);
+/* Lqbar = tril(...) + beta * Lqbar: accumulates onto a gradient that is already in place (the KL term's, or an earlier
+ * application of a tied layer) -- the product writes straight into the optimiser's gradient bucket */
+int nsgp_svgp_lqbar_acc_f32(const float* A, const float* C, const float* gvar, int64_t batch, int64_t M, int64_t n,
+                            float beta, float* Lqbar, void* ws, size_t ws_bytes, void* stream);
+int nsgp_svgp_lqbar_acc_f64(const double* A, const double* C, const double* gvar, int64_t batch, int64_t M, int64_t n,
+                            double beta, double* Lqbar, void* ws, size_t ws_bytes, void* stream);
 /* The same two steps with the layer's affine prior mean and the cheap column reductions folded in, so that the mean
  * module of models/dgps.py:40-43 (gpytorch ConstantMean / LinearMean), the `+ 1e-4` of the predictive variance and the
  * output-scale gradient cost no launches of their own:

@@ -1058,14 +1058,14 @@ int abar_impl(const T* Lq, const T* C, const T* A, const T* m, const T* gmean, c
 }
 template <typename T>
 int lqbar_impl(const T* A, const T* C, const T* gvar, int64_t batch, int64_t M, int64_t n, T* Lqbar, void* ws,
-               size_t wsb, void* stream) {
+               size_t wsb, void* stream, T beta = T(0)) {
     if (!A) return -1; if (!C) return -2; if (!gvar) return -3;
     if (batch < 0) return -4; if (M < 0) return -5; if (n < 0) return -6; if (!Lqbar) return -7;
     if (batch == 0 || M == 0) return 0;
     Epi ep{};
     ep.kind = 0; ep.ks = gvar; ep.modeA = 0; ep.modeB = 0;
     // Lqbar = tril(A diag(2 gvar) C^T):  B(k, j) = C[j][k], scaled along k by gvar, alpha = 2
-    return gemm_impl<T>(M, M, n, T(2), A, n, 1, M * n, 0, C, 1, n, M * n, 0, T(0), Lqbar, M, M * M, 0, batch, 1,
+    return gemm_impl<T>(M, M, n, T(2), A, n, 1, M * n, 0, C, 1, n, M * n, 0, beta, Lqbar, M, M * M, 0, batch, 1,
                         NSGP_GEMM_C_LOWER, ws, wsb, stream, &ep);
 }
 }  // namespace
@@ -1226,6 +1226,14 @@ int nsgp_svgp_lqbar_f32(const float* A, const float* C, const float* gvar, int64
 int nsgp_svgp_lqbar_f64(const double* A, const double* C, const double* gvar, int64_t batch, int64_t M, int64_t n,
                         double* Lqbar, void* ws, size_t ws_bytes, void* stream) {
     return lqbar_impl<double>(A, C, gvar, batch, M, n, Lqbar, ws, ws_bytes, stream);
+}
+int nsgp_svgp_lqbar_acc_f32(const float* A, const float* C, const float* gvar, int64_t batch, int64_t M, int64_t n,
+                            float beta, float* Lqbar, void* ws, size_t ws_bytes, void* stream) {
+    return lqbar_impl<float>(A, C, gvar, batch, M, n, Lqbar, ws, ws_bytes, stream, beta);
+}
+int nsgp_svgp_lqbar_acc_f64(const double* A, const double* C, const double* gvar, int64_t batch, int64_t M, int64_t n,
+                            double beta, double* Lqbar, void* ws, size_t ws_bytes, void* stream) {
+    return lqbar_impl<double>(A, C, gvar, batch, M, n, Lqbar, ws, ws_bytes, stream, beta);
 }
 
 }  // extern "C"

@@ -68,6 +68,65 @@ def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
+# --------------------------------------------------------------------------------------------
+# Gradient sinks: where a large parameter's gradient should be WRITTEN (the flat gradient bucket of nsgp.optim.FlatBucket)
+# instead of being handed to autograd in a fresh buffer and copied there afterwards.  A backward kernel that produces the
+# gradient of a registered parameter asks `grad_sink(t)` (t: the parameter as the node received it -- same storage):
+#   * (view, False): nothing is in place yet -> write the gradient into `view` and RETURN `view` as the gradient (autograd's
+#     AccumulateGrad adopts it as p.grad: the bucket is filled without a copy);
+#   * (view, True):  the view already holds a term of this gradient (the KL term, an earlier application of a tied layer,
+#     or -- gradient accumulation over several backward passes -- p.grad itself) -> ACCUMULATE into `view` and return
+#     None for that input.
+# "Already holds a term" cannot be read off p.grad inside one backward pass (the engine sums the incoming gradients of a leaf
+# in its input buffer and sets p.grad only after the LAST of them), so a sink remembers the autograd graph task that wrote
+# it first; across passes p.grad decides, so any way of clearing gradients is safe.
+# --------------------------------------------------------------------------------------------
+_grad_sinks = {}
+
+
+class _GradSink:
+    def __init__(self, param, flat_g, off):
+        import weakref
+        self.param = weakref.ref(param)
+        self.flat_g, self.off, self.numel, self.shape = flat_g, int(off), param.numel(), tuple(param.shape)
+        self.task = None                                  # id of the backward pass (graph task) that wrote first
+
+    def view(self):
+        return self.flat_g[self.off:self.off + self.numel].view(self.shape)
+
+
+def register_grad_sink(param, flat_g, off):
+    _grad_sinks[param.data_ptr()] = _GradSink(param, flat_g, off)
+
+
+def unregister_grad_sinks(flat_g):
+    for k in [k for k, v in _grad_sinks.items() if v.flat_g is flat_g]:
+        del _grad_sinks[k]
+
+
+def grad_sink(t):
+    """(view shaped like t, accumulate) for a tensor that IS a registered parameter (same storage, same number of
+    elements, contiguous) inside a backward pass, else None."""
+    s = _grad_sinks.get(t.data_ptr())
+    if s is None:
+        return None
+    task = torch._C._current_graph_task_id()
+    p = s.param()
+    if task < 0 or p is None or p.data_ptr() != t.data_ptr() or t.numel() != s.numel or not t.is_contiguous() \
+            or t.dtype != s.flat_g.dtype or t.device != s.flat_g.device:
+        return None
+    v = s.view()
+    if p.grad is not None:
+        if p.grad.data_ptr() != v.data_ptr():
+            return None                               # something else owns p.grad: the ordinary path accumulates into it
+        s.task = task
+        return v.view(t.shape), True                  # an earlier pass (or stage) left its gradient in the view
+    if s.task == task:
+        return v.view(t.shape), True                  # an earlier node of THIS pass wrote the view
+    s.task = task
+    return v.view(t.shape), False
+
+
 def _scalar_dev(v, like):
     """Host number or tensor -> 1-element device tensor of like's dtype (no sync)."""
     if torch.is_tensor(v):
@@ -681,7 +740,8 @@ def svgp_project_bwd(Lq, m, A, C, gmean, gvar, affine=None):
     lib = _lib.load()
     sfx, st = _sfx(ref), _stream()
     Abar = torch.empty_like(A)
-    Lqbar = torch.empty_like(Lq)
+    sink = grad_sink(Lq)                     # the optimiser's gradient bucket, when Lq is a registered parameter
+    Lqbar, lq_beta = (torch.empty_like(Lq), 0.0) if sink is None else (sink[0], 1.0 if sink[1] else 0.0)
     mbar = torch.empty_like(m)
     flops = 1.0 * M * M * n * batch
     basebar = torch.empty(batch, dtype=ref.dtype, device=ref.device)
@@ -704,9 +764,10 @@ def svgp_project_bwd(Lq, m, A, C, gmean, gvar, affine=None):
                              _p(Abar), st), flops, ref.dtype)
     wsb = lib.nsgp_svgp_lqbar_workspace(batch, M, n, ref.element_size())
     ws = _ws(wsb, ref.device) if wsb else None
-    _timed(lambda: _lib.call(f'nsgp_svgp_lqbar_{sfx}', _p(A), _p(C), _p(gvar), batch, M, n, _p(Lqbar), _p(ws),
+    _timed(lambda: _lib.call(f'nsgp_svgp_lqbar_acc_{sfx}', _p(A), _p(C), _p(gvar), batch, M, n, lq_beta, _p(Lqbar), _p(ws),
                              ws.numel() if ws is not None else 0, st), flops, ref.dtype)
-    return Abar, Lqbar, mbar, basebar, wbar, cbar
+    # accumulated onto a gradient that is already p.grad: nothing to hand to autograd for Lq
+    return Abar, (None if lq_beta else Lqbar), mbar, basebar, wbar, cbar
 
 
 def dgp_sample(mean, var, eps):
@@ -1094,7 +1155,9 @@ class KlWhitenedTotalFn(torch.autograd.Function):
     def backward(ctx, g):
         m2, L2 = ctx.saved_tensors
         batch, M = m2.shape
-        gm, gL = torch.empty_like(m2), torch.empty_like(L2)
+        sink = grad_sink(L2)                 # first writer of the gradient bucket's range for Lq (see grad_sink)
+        gm = torch.empty_like(m2)
+        gL = sink[0] if (sink is not None and not sink[1]) else torch.empty_like(L2)
         _lib.call(f'nsgp_kl_whitened_total_bwd_{_sfx(m2)}', _p(m2), _p(L2), batch, M, ctx.scale, _p(_c(g).reshape(1)),
                   _p(gm), _p(gL), _stream())
         return gm.reshape(ctx.shapes[0]), gL.reshape(ctx.shapes[1]), None, (g if ctx.has_addin else None)

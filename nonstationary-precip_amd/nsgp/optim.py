@@ -60,12 +60,25 @@ class FlatBucket:
                 p.grad = self.flat_g[off:off + n].view(p.shape) if grads_as_views else None
                 self.offsets.append((off, n))
         self.grad_views = [self.flat_g[off:off + n].view(p.shape) for p, (off, n) in zip(plist, self.offsets)]
+        # large parameters on the GPU: their backward kernels write the gradient straight into the bucket (ops.grad_sink)
+        # instead of a fresh buffer that gather_grads() would copy (the three 1024 x 1024 Cholesky factors of the headline
+        # model are 12 of the bucket's 12.6 MB)
+        if not grads_as_views and dev.type == 'cuda':
+            for p, (off, n) in zip(plist, self.offsets):
+                if n >= (1 << 16):
+                    ops.register_grad_sink(p, self.flat_g, off)
         self.stage_index = [0 if stage_of is None else int(stage_of.get(id(p), 0)) for p in plist]
         self.segments = {}                                             # stage -> (first element, one past the last)
         for k, (off, n) in zip(self.stage_index, self.offsets):
             end = (off + n + ALIGN - 1) // ALIGN * ALIGN                # the padding travels with its parameter
             a, b = self.segments.get(k, (off, off))
             self.segments[k] = (min(a, off), max(b, end))
+
+    def __del__(self):
+        try:
+            ops.unregister_grad_sinks(self.flat_g)
+        except Exception:
+            pass
 
     def unpadded(self, flat):
         """The parameters' elements of a bucket-shaped buffer (flat_p, flat_g, an Adam moment) without the alignment

@@ -188,3 +188,73 @@ def test_bench_two_rank_control_flow_matches_one_rank():
     weak = _bench_line(2, ['--scaling', 'weak'], _free_port())
     assert weak['scaling'] == 'weak' and weak['config']['global_batch'] == 8192
     assert weak['value'] == pytest.approx(2 * weak['iterations_per_sec'], rel=1e-3)
+
+
+def test_gradient_sinks_fill_the_bucket_without_a_copy_and_match_plain_autograd():
+    """FlatBucket(grads_as_views=False) registers its large parameters as gradient sinks: the KL term's and the layers'
+    Lq gradients are written / accumulated straight into the bucket range (no gather copy), in whatever order the engine
+    runs them, for tied layers, across two backward passes without zero_grad, and after gradients were cleared by hand.
+    Reference: the same model with an ordinary torch optimiser layout (no bucket)."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, 'nonstationary-precip_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import models.dgps as m
+    from nsgp.dist import PhiloxEps
+    from nsgp.gp import settings
+    from nsgp.gp.mlls import DeepApproximateMLL, VariationalELBO
+    from nsgp.optim import FlatBucket
+
+    def build(layers):
+        torch.manual_seed(3)
+        m.num_output_dims = 3 if layers > 1 else 2         # a tied hidden layer maps 3 -> 3 (module-level knob, as upstream)
+        model = m.DeepGP(layers, (600, 3), num_inducing=256).cuda()        # 256 x 256 factors: above the sink threshold
+        mll = DeepApproximateMLL(VariationalELBO(model.likelihood, model, 600))
+        model.train()
+        return model, mll
+
+    g = torch.Generator().manual_seed(9)
+    x, y = torch.randn(192, 3, generator=g).cuda(), torch.randn(192, generator=g).cuda()
+
+    def grads(model, mll, passes, bucket=None, clear_by_hand=False):
+        out = None
+        for rep in range(2):                              # second repetition: after gradients were cleared
+            if bucket is not None and not clear_by_hand:
+                bucket.zero_grad()
+            else:
+                for p in model.parameters():
+                    p.grad = None
+            for _ in range(passes):
+                with settings.num_likelihood_samples(3), settings.eps_provider(PhiloxEps(5)):
+                    loss = -mll(model(x), y)
+                loss.backward()
+            if bucket is not None:
+                bucket.gather_grads()
+                out = {n: bucket.flat_g[off:off + k].view(p.shape).clone()
+                       for (n, p), (off, k) in zip([(names[id(q)], q) for q in bucket.params], bucket.offsets)}
+            else:
+                out = {n: p.grad.clone() for n, p in model.named_parameters()}
+        return out
+
+    for layers in (1, 2):                                  # 2: the tied hidden layer is applied twice
+        for passes in (1, 2):
+            for by_hand in (False, True):
+                ref_model, ref_mll = build(layers)
+                ref = grads(ref_model, ref_mll, passes)
+                model, mll = build(layers)
+                names = {id(p): n for n, p in model.named_parameters()}
+                bucket = FlatBucket(model.parameters(), grads_as_views=False)
+                got = grads(model, mll, passes, bucket, clear_by_hand=by_hand)
+                big = [n for n, p in model.named_parameters() if p.numel() >= (1 << 16)]
+                assert big
+                for n in big:                              # adopted: p.grad lives in the bucket, nothing was copied
+                    p = dict(model.named_parameters())[n]
+                    idx = [i for i, q in enumerate(bucket.params) if q is p][0]
+                    assert p.grad is not None and p.grad.data_ptr() == bucket.grad_views[idx].data_ptr()
+                for n in ref:
+                    assert torch.allclose(got[n], ref[n], rtol=2e-5, atol=1e-6), (layers, passes, by_hand, n)
+                del bucket
+    m.num_output_dims = 2
