@@ -527,10 +527,15 @@ int potrf_impl(T* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int32_t*
     hipStream_t st = (hipStream_t)stream;
     const size_t step_lds = (4 * (size_t)NB * LDD + 4 * SB * LDI + NB) * sizeof(T);
     nsgp_opt_in_lds((const void*)potrf_step_kernel<T>, step_lds);
-    // Two-level blocking for large matrices: rank-64 updates stay inside a 256-column outer panel (they are
+    // Two-level blocking for large matrices: rank-64 updates stay inside an outer panel of NB2 columns (they are
     // HBM-bound: 8 flop/B in float64), the rest of the trailing matrix is updated once per outer panel with
-    // K = 256.  Small matrices (the DSVI Kzz, n ~ 1024) are latency-bound and use one level.
-    const int64_t NB2 = n >= 2048 ? 4 * NB : n;
+    // K = NB2.  Matrices up to n = 2048 (the DSVI Kzz, n ~ 1024) are latency-bound and use one level.
+    // Outer panel width (measured, float64, MI355X): n = 2048: 985 / 954 / 921 / 878 us at 256 / 512 / 1024 / one level;
+    // n = 4096: 2316 / 2245 / 2166 / 2147 us at 256 / 512 / 1024 / 2048; n = 8192: 7.53 / 6.99 / 7.02 / 7.53 ms;
+    // n = 16384: 37.7 / 35.8 / 35.9 ms at 256 / 512 / 1024.  NSGP_POTRF_NB2 (units of 64 columns) overrides for A/B runs.
+    const char* nb2e = getenv("NSGP_POTRF_NB2");
+    const int64_t nb2m = (nb2e && atoi(nb2e) > 0) ? atoi(nb2e) : (n <= 4096 ? 32 : 16);
+    const int64_t NB2 = n > 2048 ? nb2m * NB : n;
     for (int64_t J0 = 0; J0 < n; J0 += NB2) {
         const int64_t Jend = (J0 + NB2) < n ? (J0 + NB2) : n;
         for (int64_t j0 = J0; j0 < Jend; j0 += NB) {
