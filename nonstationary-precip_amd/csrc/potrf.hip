@@ -369,6 +369,222 @@ __device__ __forceinline__ void panel_body(unsigned char* panel_smem, T* __restr
         if (w * SB + i < rows) Ab[(r0 + w * SB + i) * lda + j0 + lane] = Xw[i * LDD + lane];
 }
 
+// LDS traffic written and re-read by ONE wave (other lanes): the LDS executes a wave's instructions in order, the fence
+// only stops the compiler from moving them across (and drains lgkmcnt)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// C(16 x 16 tile at Ct) -= A(16 rows at Ar) B(16 rows at Br)^T over K = 64, everything in LDS with leading dimension LDD
+template <typename T>
+__device__ __forceinline__ void rank64_tile(T* Ct, const T* Ar, const T* Br, int lane) {
+    typedef Mma16<T> MM;
+    const int fm = lane & 15, fk = lane >> 4;
+    typename MM::acc_t acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = Ct[MM::crow(r, lane) * LDD + fm];
+#pragma unroll
+    for (int kk = 0; kk < NB / 4; ++kk) acc = MM::mma(-Ar[fm * LDD + 4 * kk + fk], Br[fm * LDD + 4 * kk + fk], acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ct[MM::crow(r, lane) * LDD + fm] = acc[r];
+}
+
+// One column block CB of the blocked substitution  X L11^T = A21  for the 16-row strip Xw of the slab, by ONE wave:
+// X_cb = (A_cb - sum_{kb < cb} X_kb L[cb][kb]^T) Dinv_cb^T
+template <typename T, int CB>
+__device__ __forceinline__ void slab_subst_step(T* Xw, const T* S, const T* Dinv, int lane) {
+    typedef Mma16<T> MM;
+    const int fm = lane & 15, fk = lane >> 4;
+    typename MM::acc_t acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = Xw[MM::crow(r, lane) * LDD + CB * SB + fm];
+#pragma unroll
+    for (int kb = 0; kb < CB; ++kb)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            acc = MM::mma(-Xw[fm * LDD + kb * SB + 4 * kk + fk], S[(CB * SB + fm) * LDD + kb * SB + 4 * kk + fk], acc);
+    wave_sync();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Xw[MM::crow(r, lane) * LDD + CB * SB + fm] = acc[r];
+    wave_sync();
+    typename MM::acc_t y = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+        y = MM::mma(Xw[fm * LDD + CB * SB + 4 * kk + fk], Dinv[(CB * SB + fm) * LDI + 4 * kk + fk], y);
+    wave_sync();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Xw[MM::crow(r, lane) * LDD + CB * SB + fm] = y[r];
+    wave_sync();
+}
+
+// Panel with the idle waves put to work.  While wave 0 factors a 16-column sub-panel in registers (2.7 us, 4 times per
+// panel) the other three waves used to wait at the barrier; here they run everything that does not depend on the
+// sub-panel being factored:
+//   F0: the previous panel's rank-64 update of columns 16..63 of the diagonal block (columns 0..15, which sub-panel 0
+//       needs, are updated by all waves first);
+//   F1: that update on the slab (X -= Q P^T), wave 1 also inverts diagonal sub-block 0;
+//   F2, F3: column blocks 0 and 1 of the slab substitution (wave 1 inverts sub-blocks 1, 2);
+// so that after the last sub-panel only sub-block 3's inverse, column blocks 2 and 3 of the substitution and the store
+// remain (5.5 -> ~2 us) -- same arithmetic in the same order per element as panel_body, bit-identical results.
+// Work on a slab strip is wave-local (wave_sync); every phase ends in ONE barrier that all four waves reach.
+template <typename T>
+__device__ __forceinline__ void panel_body2(unsigned char* panel_smem, T* __restrict__ A, int64_t n, int64_t lda,
+                                            int64_t sA, int64_t j0, T* __restrict__ wsL, int64_t npanels,
+                                            int32_t* __restrict__ info, int64_t blk, int64_t b, bool pre) {
+    typedef Mma16<T> MM;
+    typedef typename MM::acc_t acc_t;
+    T* S = reinterpret_cast<T*>(panel_smem);            // [64][LDD]   diagonal block -> L11
+    T* Xs = S + NB * LDD;                               // [64][LDD]   this workgroup's slab
+    T* Dinv = Xs + NB * LDD;                            // [4][16][LDI] inverses of the 16x16 diagonal sub-blocks
+    T* rd = Dinv + 4 * SB * LDI;                        // [64] reciprocal pivots
+    T* Ps = rd + NB;                                    // [64][LDD]   previous panel's L, diagonal-block rows
+    T* Qs = Ps + NB * LDD;                              // [64][LDD]   previous panel's L, slab rows
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    T* Ab = A + b * sA;
+    const int64_t pj = j0 / NB;
+    const int64_t r0 = j0 + NB + blk * NB;
+    const int rows = r0 >= n ? 0 : (int)((n - r0) < NB ? (n - r0) : NB);
+    const int fm = lane & 15, fk = lane >> 4;
+    {
+        T dr[SB], xr[SB], pr[SB], qr[SB];                // loads first, LDS stores after (one exposed latency)
+#pragma unroll
+        for (int i = 0; i < SB; ++i) dr[i] = Ab[(j0 + w * SB + i) * lda + j0 + lane];
+#pragma unroll
+        for (int i = 0; i < SB; ++i) {                   // clamped row: unconditional loads (no branch per load)
+            const int64_t rr = r0 + w * SB + i;
+            xr[i] = Ab[(rr < n ? rr : n - 1) * lda + j0 + lane];
+        }
+        if (pre) {
+#pragma unroll
+            for (int i = 0; i < SB; ++i) {
+                const int64_t rr = r0 + w * SB + i;
+                pr[i] = Ab[(j0 + w * SB + i) * lda + j0 - NB + lane];
+                qr[i] = Ab[(rr < n ? rr : n - 1) * lda + j0 - NB + lane];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < SB; ++i) { keep(dr[i]); keep(xr[i]); }
+        if (pre) {
+#pragma unroll
+            for (int i = 0; i < SB; ++i) { keep(pr[i]); keep(qr[i]); }
+        }
+#pragma unroll
+        for (int i = 0; i < SB; ++i) {
+            S[(w * SB + i) * LDD + lane] = dr[i];
+            Xs[(w * SB + i) * LDD + lane] = (w * SB + i) < rows ? xr[i] : T(0);
+            if (pre) {
+                Ps[(w * SB + i) * LDD + lane] = pr[i];
+                Qs[(w * SB + i) * LDD + lane] = (w * SB + i) < rows ? qr[i] : T(0);
+            }
+        }
+    }
+    __syncthreads();
+    if (pre) {                                           // U0: columns 0..15 of S -= P P^T (what sub-panel 0 needs)
+        rank64_tile<T>(S + (w * SB) * LDD, Ps + (w * SB) * LDD, Ps, lane);
+        __syncthreads();
+    }
+    const bool slab = rows > 0;
+    int bad = 0;
+    // ---- F0 ----
+    if (w == 0) { const int bd = factor_subpanel<T, 0>(S, rd, lane); if (bad == 0) bad = bd; }
+    else if (pre) {
+        for (int q = w - 1; q < 12; q += 3) {            // (row block, column tile 1..3) of S -= P P^T
+            const int rb = q / 3, t = 1 + q % 3;
+            rank64_tile<T>(S + (rb * SB) * LDD + t * SB, Ps + (rb * SB) * LDD, Ps + (t * SB) * LDD, lane);
+        }
+    }
+    __syncthreads();
+#define NSGP_TRAIL(C0)                                                                                \
+    {                                                                                                 \
+        constexpr int B0 = C0 / SB;                                                                   \
+        constexpr int NT = (3 - B0) * (4 - B0) / 2;      /* lower tiles of the trailing block */      \
+        for (int q = w; q < NT; q += 4) {                                                             \
+            int ti = B0 + 1, tj = B0 + 1, c = q;                                                      \
+            while (c > ti - (B0 + 1)) { c -= ti - B0; ++ti; }                                         \
+            tj = B0 + 1 + c;                                                                          \
+            acc_t acc;                                                                                \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r)                                             \
+                acc[r] = S[(ti * SB + MM::crow(r, lane)) * LDD + tj * SB + fm];                       \
+            _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                        \
+                const T av = -S[(ti * SB + fm) * LDD + C0 + 4 * kk + fk];                             \
+                const T bv = S[(tj * SB + fm) * LDD + C0 + 4 * kk + fk];                              \
+                acc = MM::mma(av, bv, acc);                                                           \
+            }                                                                                         \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r)                                             \
+                S[(ti * SB + MM::crow(r, lane)) * LDD + tj * SB + fm] = acc[r];                       \
+        }                                                                                             \
+        if (NT > 0) __syncthreads();                                                                  \
+    }
+    NSGP_TRAIL(0)
+    // ---- F1 ----
+    if (w == 0) { const int bd = factor_subpanel<T, 16>(S, rd, lane); if (bad == 0) bad = bd; }
+    else {
+        // X -= Q P^T, 16 (strip, column tile) tasks over F1 and F2: column tiles 0 and 1 now (waves 2, 3: the substitution
+        // needs them first), tile 2 by wave 1 behind its inversions, tile 3 in F2
+        auto xtile = [&](int rb, int t) __attribute__((always_inline)) {
+            rank64_tile<T>(Xs + (rb * SB) * LDD + t * SB, Qs + (rb * SB) * LDD, Ps + (t * SB) * LDD, lane);
+        };
+        if (w == 1) {
+            invert_subblock<T>(S, rd, Dinv, 0, lane);
+            if (pre && slab) { xtile(0, 2); xtile(1, 2); }
+        } else if (pre && slab) {
+            for (int rb = 0; rb < 4; ++rb) xtile(rb, w - 2);
+        }
+    }
+    __syncthreads();
+    NSGP_TRAIL(16)
+    // ---- F2 ----
+    if (w == 0) { const int bd = factor_subpanel<T, 32>(S, rd, lane); if (bad == 0) bad = bd; }
+    else {
+        auto xtile = [&](int rb, int t) __attribute__((always_inline)) {
+            rank64_tile<T>(Xs + (rb * SB) * LDD + t * SB, Qs + (rb * SB) * LDD, Ps + (t * SB) * LDD, lane);
+        };
+        if (w == 1) {
+            invert_subblock<T>(S, rd, Dinv, 1, lane);
+            if (pre && slab) { xtile(2, 2); xtile(3, 2); }
+        } else if (slab) {                               // waves 2, 3: strips {0, 2} and {1, 3}
+            if (pre) { xtile(w - 2, 3); xtile(w, 3); }
+            slab_subst_step<T, 0>(Xs + ((w - 2) * SB) * LDD, S, Dinv, lane);
+            slab_subst_step<T, 0>(Xs + ((w) * SB) * LDD, S, Dinv, lane);
+        }
+    }
+    __syncthreads();
+    NSGP_TRAIL(32)
+    // ---- F3 ----
+    if (w == 0) { const int bd = factor_subpanel<T, 48>(S, rd, lane); if (bad == 0) bad = bd; }
+    else if (w == 1) invert_subblock<T>(S, rd, Dinv, 2, lane);
+    else if (slab) {
+        slab_subst_step<T, 1>(Xs + ((w - 2) * SB) * LDD, S, Dinv, lane);
+        slab_subst_step<T, 1>(Xs + ((w) * SB) * LDD, S, Dinv, lane);
+    }
+    __syncthreads();
+#undef NSGP_TRAIL
+    // ---- after the last sub-panel ----
+    if (w == 1) invert_subblock<T>(S, rd, Dinv, 3, lane);
+    else if (w >= 2 && slab) {
+        slab_subst_step<T, 2>(Xs + ((w - 2) * SB) * LDD, S, Dinv, lane);
+        slab_subst_step<T, 2>(Xs + ((w) * SB) * LDD, S, Dinv, lane);
+    }
+    if (blk == 0) {
+        T* dst = wsL + (b * npanels + pj) * NB * NB;
+#pragma unroll
+        for (int i = 0; i < SB; ++i) dst[(w * SB + i) * NB + lane] = S[(w * SB + i) * LDD + lane];
+        // the first panel initialises info (no memset launch); later panels record only the first failure
+        if (tid == 0) {
+            if (j0 == 0) info[b] = bad ? (int32_t)bad : 0;
+            else if (bad && info[b] == 0) info[b] = (int32_t)(j0 + bad);
+        }
+    }
+    __syncthreads();
+    if (!slab) return;                                   // workgroup-uniform
+    T* Xw = Xs + (w * SB) * LDD;                         // last column block: every wave its own strip
+    slab_subst_step<T, 3>(Xw, S, Dinv, lane);
+#pragma unroll
+    for (int i = 0; i < SB; ++i)
+        if (w * SB + i < rows) Ab[(r0 + w * SB + i) * lda + j0 + lane] = Xw[i * LDD + lane];
+}
+
 // Rank-64 trailing update  C -= L21 L21^T  on the lower 64x64 tiles of a (rows x wcols) region, one tile per
 // workgroup, ONE K step: both operand blocks and the C tile are requested up front (a single memory
 // latency), then 16 MFMA k-steps per 16x16 tile.  The generic GEMM pays a load latency per BK=16 K-tile
@@ -461,7 +677,11 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ A, int6
                                                          int64_t wcols) {
     extern __shared__ __attribute__((aligned(16))) unsigned char panel_smem[];
     const int64_t blk = blockIdx.x, b = blockIdx.y;
-    if (blk < nslab) panel_body<T>(panel_smem, A, n, lda, sA, j0, wsL, npanels, info, blk, b, pre != 0);
+    if (blk < nslab) {
+        // bit 1 of `pre`: the round-1 panel (NSGP_POTRF_PANEL=1), kept for A/B timing
+        if (pre & 2) panel_body<T>(panel_smem, A, n, lda, sA, j0, wsL, npanels, info, blk, b, (pre & 1) != 0);
+        else panel_body2<T>(panel_smem, A, n, lda, sA, j0, wsL, npanels, info, blk, b, (pre & 1) != 0);
+    }
     else syrk_body<T>(panel_smem, A, n, lda, sA, j0 - NB, j0 + NB, wcols, blk - nslab, b);
 }
 
@@ -533,6 +753,8 @@ int potrf_impl(T* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int32_t*
     // Outer panel width (measured, float64, MI355X): n = 2048: 985 / 954 / 921 / 878 us at 256 / 512 / 1024 / one level;
     // n = 4096: 2316 / 2245 / 2166 / 2147 us at 256 / 512 / 1024 / 2048; n = 8192: 7.53 / 6.99 / 7.02 / 7.53 ms;
     // n = 16384: 37.7 / 35.8 / 35.9 ms at 256 / 512 / 1024.  NSGP_POTRF_NB2 (units of 64 columns) overrides for A/B runs.
+    const char* pve = getenv("NSGP_POTRF_PANEL");
+    const int old_panel = (pve && pve[0] == '1') ? 2 : 0;
     const char* nb2e = getenv("NSGP_POTRF_NB2");
     const int64_t nb2m = (nb2e && atoi(nb2e) > 0) ? atoi(nb2e) : (n <= 4096 ? 32 : 16);
     const int64_t NB2 = n > 2048 ? nb2m * NB : n;
@@ -556,7 +778,7 @@ int potrf_impl(T* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int32_t*
                 ntile = tn * (tn + 1) / 2 + (tm - tn) * tn;
             }
             hipLaunchKernelGGL((potrf_step_kernel<T>), dim3((unsigned)(nslab + ntile), (unsigned)batch), dim3(256),
-                               step_lds, st, A, n, lda, sA, j0, wsL, npanels, info, nslab, pre, wcols);
+                               step_lds, st, A, n, lda, sA, j0, wsL, npanels, info, nslab, pre | old_panel, wcols);
         }
         if (Jend < n) {
             const int64_t rest = n - Jend, kw = Jend - J0;
