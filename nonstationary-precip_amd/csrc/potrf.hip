@@ -685,6 +685,272 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ A, int6
     else syrk_body<T>(panel_smem, A, n, lda, sA, j0 - NB, j0 + NB, wcols, blk - nslab, b);
 }
 
+// ---- the inverse accumulated inside the factorisation's launches (nsgp_potrf_trtri, n a multiple of 64, one level) -----------
+// W = L^-1 is the identity carried through the same block eliminations:  after panel j,
+//     W[j][0..j]  <-  L_jj^-1 W[j][0..j]                (row block j: a 64-row triangular solve per 64-column chunk)
+//     W[i][0..j]  -=  L[i][j] W[j][0..j]   for i > j    (rank-64 update: tiles with one K step, like the trailing update)
+// The row-block solves run as extra workgroups of panel j's launch (they factor the diagonal block redundantly like the slab
+// workgroups, so they add no latency), the updates as extra tiles of panel j + 1's launch, next to the trailing update of
+// the factor -- on CUs those launches leave idle.  The eight latency-bound launches of the recursive inverse (trtri: 162 us
+// for 3 x 1024^2) disappear from the DSVI whitening chain.
+
+// C(16 x 16 tile at Ct) -= A(16 rows at Ar, K contiguous) B(64 x 16 at Bk, K-major: B(k, n) = Bk[k * LDD + n])
+template <typename T>
+__device__ __forceinline__ void rank64_tile_kn(T* Ct, const T* Ar, const T* Bk, int lane) {
+    typedef Mma16<T> MM;
+    const int fm = lane & 15, fk = lane >> 4;
+    typename MM::acc_t acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = Ct[MM::crow(r, lane) * LDD + fm];
+#pragma unroll
+    for (int kk = 0; kk < NB / 4; ++kk) acc = MM::mma(-Ar[fm * LDD + 4 * kk + fk], Bk[(4 * kk + fk) * LDD + fm], acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ct[MM::crow(r, lane) * LDD + fm] = acc[r];
+}
+
+// Row block RB of the blocked substitution  L11 Y = R  for the 16-COLUMN strip Rc of a 64 x 64 block, by ONE wave:
+// Y_rb = Dinv_rb (R_rb - sum_{kb < rb} L[rb][kb] Y_kb)      (Y overwrites R; Rc points at the strip's first column)
+template <typename T, int RB>
+__device__ __forceinline__ void prow_subst_step(T* Rc, const T* S, const T* Dinv, int lane) {
+    typedef Mma16<T> MM;
+    const int fm = lane & 15, fk = lane >> 4;
+    typename MM::acc_t acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = Rc[(RB * SB + MM::crow(r, lane)) * LDD + fm];
+#pragma unroll
+    for (int kb = 0; kb < RB; ++kb)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            acc = MM::mma(-S[(RB * SB + fm) * LDD + kb * SB + 4 * kk + fk], Rc[(kb * SB + 4 * kk + fk) * LDD + fm], acc);
+    wave_sync();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Rc[(RB * SB + MM::crow(r, lane)) * LDD + fm] = acc[r];
+    wave_sync();
+    typename MM::acc_t y = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+        y = MM::mma(Dinv[(RB * SB + fm) * LDI + 4 * kk + fk], Rc[(RB * SB + 4 * kk + fk) * LDD + fm], y);
+    wave_sync();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Rc[(RB * SB + MM::crow(r, lane)) * LDD + fm] = y[r];
+    wave_sync();
+}
+
+// Row block j of the inverse, 64-column chunk c (c0 = 64 c <= j0):  W[j][c] <- L_jj^-1 (W[j][c] - L[j][j-1] W[j-1][c]).
+// Same phases as panel_body2 (the diagonal block is factored redundantly; the idle waves do the chunk's work).
+template <typename T>
+__device__ __forceinline__ void prow_body(unsigned char* panel_smem, const T* __restrict__ A, int64_t n, int64_t lda,
+                                          int64_t sA, int64_t j0, T* __restrict__ X, int64_t ldx, int64_t sX, int64_t c,
+                                          int64_t b, bool pre) {
+    typedef Mma16<T> MM;
+    typedef typename MM::acc_t acc_t;
+    T* S = reinterpret_cast<T*>(panel_smem);            // [64][LDD]   diagonal block -> L11
+    T* Rs = S + NB * LDD;                               // [64][LDD]   the chunk of W's row block
+    T* Dinv = Rs + NB * LDD;                            // [4][16][LDI]
+    T* rd = Dinv + 4 * SB * LDI;                        // [64]
+    T* Ps = rd + NB;                                    // [64][LDD]   L[j][j-1]
+    T* Qs = Ps + NB * LDD;                              // [64][LDD]   W[j-1][c]   (K x N)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const T* Ab = A + b * sA;
+    T* Xb = X + b * sX;
+    const int64_t c0 = c * NB;
+    const bool diag = c0 == j0;                          // the chunk that starts as the identity
+    const bool upd = pre && !diag;                       // chunks left of the diagonal carry the previous panel's update
+    const bool first = c0 + NB == j0;                    // chunk j - 1: no earlier update has written it
+    const int fm = lane & 15, fk = lane >> 4;
+    if (diag) {                                          // zero the rest of these rows (W is lower triangular); off the
+        for (int i = w; i < NB; i += 4)                  // critical path: this workgroup has no chunk to load
+            for (int64_t cc = j0 + NB + lane; cc < n; cc += 64) Xb[(j0 + i) * ldx + cc] = T(0);
+    }
+    {
+        T dr[SB], xr[SB], pr[SB], qr[SB];
+#pragma unroll
+        for (int i = 0; i < SB; ++i) dr[i] = Ab[(j0 + w * SB + i) * lda + j0 + lane];
+#pragma unroll
+        for (int i = 0; i < SB; ++i)            // identity on the diagonal; zero where no update has reached yet (W is never
+            xr[i] = diag ? ((w * SB + i) == lane ? T(1) : T(0))          // initialised: chunk j - 1 is touched for the first
+                         : (first ? T(0) : Xb[(j0 + w * SB + i) * ldx + c0 + lane]);   // time by panel j - 1's update)
+        if (pre) {
+#pragma unroll
+            for (int i = 0; i < SB; ++i) pr[i] = Ab[(j0 + w * SB + i) * lda + j0 - NB + lane];
+        }
+        if (upd) {
+#pragma unroll
+            for (int i = 0; i < SB; ++i) qr[i] = Xb[(j0 - NB + w * SB + i) * ldx + c0 + lane];
+        }
+#pragma unroll
+        for (int i = 0; i < SB; ++i) { keep(dr[i]); keep(xr[i]); }
+        if (pre) {
+#pragma unroll
+            for (int i = 0; i < SB; ++i) keep(pr[i]);
+        }
+        if (upd) {
+#pragma unroll
+            for (int i = 0; i < SB; ++i) keep(qr[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < SB; ++i) {
+            S[(w * SB + i) * LDD + lane] = dr[i];
+            Rs[(w * SB + i) * LDD + lane] = xr[i];
+            if (pre) Ps[(w * SB + i) * LDD + lane] = pr[i];
+            if (upd) Qs[(w * SB + i) * LDD + lane] = qr[i];
+        }
+    }
+    __syncthreads();
+    if (pre) {                                           // U0: columns 0..15 of S -= P P^T
+        rank64_tile<T>(S + (w * SB) * LDD, Ps + (w * SB) * LDD, Ps, lane);
+        __syncthreads();
+    }
+    // ---- F0 ----
+    if (w == 0) (void)factor_subpanel<T, 0>(S, rd, lane);
+    else if (pre) {
+        for (int q = w - 1; q < 12; q += 3) {
+            const int rb = q / 3, t = 1 + q % 3;
+            rank64_tile<T>(S + (rb * SB) * LDD + t * SB, Ps + (rb * SB) * LDD, Ps + (t * SB) * LDD, lane);
+        }
+    }
+    __syncthreads();
+#define NSGP_TRAIL(C0)                                                                                \
+    {                                                                                                 \
+        constexpr int B0 = C0 / SB;                                                                   \
+        constexpr int NT = (3 - B0) * (4 - B0) / 2;                                                   \
+        for (int q = w; q < NT; q += 4) {                                                             \
+            int ti = B0 + 1, tj = B0 + 1, cq = q;                                                     \
+            while (cq > ti - (B0 + 1)) { cq -= ti - B0; ++ti; }                                       \
+            tj = B0 + 1 + cq;                                                                         \
+            acc_t acc;                                                                                \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r)                                             \
+                acc[r] = S[(ti * SB + MM::crow(r, lane)) * LDD + tj * SB + fm];                       \
+            _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                        \
+                const T av = -S[(ti * SB + fm) * LDD + C0 + 4 * kk + fk];                             \
+                const T bv = S[(tj * SB + fm) * LDD + C0 + 4 * kk + fk];                              \
+                acc = MM::mma(av, bv, acc);                                                           \
+            }                                                                                         \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r)                                             \
+                S[(ti * SB + MM::crow(r, lane)) * LDD + tj * SB + fm] = acc[r];                       \
+        }                                                                                             \
+        if (NT > 0) __syncthreads();                                                                  \
+    }
+    NSGP_TRAIL(0)
+    // R -= L[j][j-1] W[j-1][c]: tile (row block rb, column tile t)
+    auto rtile = [&](int rb, int t) __attribute__((always_inline)) {
+        rank64_tile_kn<T>(Rs + (rb * SB) * LDD + t * SB, Ps + (rb * SB) * LDD, Qs + t * SB, lane);
+    };
+    // ---- F1 ----  (the substitution walks row blocks 0, 1, 2, 3 of EVERY column strip: all column tiles of row blocks 0
+    // and 1 first)
+    if (w == 0) (void)factor_subpanel<T, 16>(S, rd, lane);
+    else if (w == 1) {
+        invert_subblock<T>(S, rd, Dinv, 0, lane);
+        if (upd) { rtile(2, 0); rtile(2, 1); }
+    } else if (upd) {
+        for (int t = 0; t < 4; ++t) rtile(w - 2, t);
+    }
+    __syncthreads();
+    NSGP_TRAIL(16)
+    // ---- F2 ----
+    if (w == 0) (void)factor_subpanel<T, 32>(S, rd, lane);
+    else if (w == 1) {
+        invert_subblock<T>(S, rd, Dinv, 1, lane);
+        if (upd) { rtile(2, 2); rtile(2, 3); }
+    } else {
+        if (upd) { rtile(3, 2 * (w - 2)); rtile(3, 2 * (w - 2) + 1); }
+        prow_subst_step<T, 0>(Rs + (w - 2) * SB, S, Dinv, lane);          // column strips {0, 2} and {1, 3}
+        prow_subst_step<T, 0>(Rs + (w) * SB, S, Dinv, lane);
+    }
+    __syncthreads();
+    NSGP_TRAIL(32)
+    // ---- F3 ----
+    if (w == 0) (void)factor_subpanel<T, 48>(S, rd, lane);
+    else if (w == 1) invert_subblock<T>(S, rd, Dinv, 2, lane);
+    else {
+        prow_subst_step<T, 1>(Rs + (w - 2) * SB, S, Dinv, lane);
+        prow_subst_step<T, 1>(Rs + (w) * SB, S, Dinv, lane);
+    }
+    __syncthreads();
+#undef NSGP_TRAIL
+    if (w == 1) invert_subblock<T>(S, rd, Dinv, 3, lane);
+    else if (w >= 2) {
+        prow_subst_step<T, 2>(Rs + (w - 2) * SB, S, Dinv, lane);
+        prow_subst_step<T, 2>(Rs + (w) * SB, S, Dinv, lane);
+    }
+    __syncthreads();
+    prow_subst_step<T, 3>(Rs + w * SB, S, Dinv, lane);                    // last row block: every wave its column strip
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SB; ++i) Xb[(j0 + w * SB + i) * ldx + c0 + lane] = Rs[(w * SB + i) * LDD + lane];
+}
+
+// W[i][c] -= L[i][j-1] W[j-1][c]  for one 64 x 64 tile (row block i >= j + 1 given by r0, chunk c0 <= j0 - 64); kp = j0 - 64.
+template <typename T>
+__device__ __forceinline__ void pupd_body(unsigned char* panel_smem, const T* __restrict__ A, int64_t lda, int64_t sA,
+                                          T* __restrict__ X, int64_t ldx, int64_t sX, int64_t kp, int64_t r0, int64_t c0,
+                                          int64_t b) {
+    typedef Mma16<T> MM;
+    typedef typename MM::acc_t acc_t;
+    T* As = reinterpret_cast<T*>(panel_smem);           // [64][LDD]  L[i][j-1]
+    T* Bs = As + NB * LDD;                              // [64][LDD]  W[j-1][c]  (K x N)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int fm = lane & 15, fk = lane >> 4;
+    const T* Ab = A + b * sA;
+    T* Xb = X + b * sX;
+    acc_t acc[4];
+    T ar[SB], br[SB];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)              // chunk j - 1 is written here for the first time (W starts as the identity)
+            acc[t][r] = c0 == kp ? T(0) : Xb[(r0 + w * SB + MM::crow(r, lane)) * ldx + c0 + t * SB + fm];
+#pragma unroll
+    for (int i = 0; i < SB; ++i) {
+        ar[i] = Ab[(r0 + w * SB + i) * lda + kp + lane];
+        br[i] = Xb[(kp + w * SB + i) * ldx + c0 + lane];
+    }
+#pragma unroll
+    for (int i = 0; i < SB; ++i) { keep(ar[i]); keep(br[i]); }
+#pragma unroll
+    for (int i = 0; i < SB; ++i) {
+        As[(w * SB + i) * LDD + lane] = ar[i];
+        Bs[(w * SB + i) * LDD + lane] = br[i];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { T v = acc[t][r]; keep(v); acc[t][r] = v; }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < NB / 4; ++kk) {
+        const T av = -As[(w * SB + fm) * LDD + 4 * kk + fk];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = MM::mma(av, Bs[(4 * kk + fk) * LDD + t * SB + fm], acc[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Xb[(r0 + w * SB + MM::crow(r, lane)) * ldx + c0 + t * SB + fm] = acc[t][r];
+}
+
+// One launch per panel of the factor-and-invert chain.  blockIdx.x ranges: [0, nslab) slab workgroups (factor + L21),
+// [.., + nprow) chunks of W's row block j, [.., + nsyrk) the previous panel's trailing update of the factor, the rest: the
+// previous panel's update of W's rows below j (tiles (row block, chunk), chunk fastest).
+template <typename T>
+__global__ __launch_bounds__(256) void potrf_inv_step_kernel(T* __restrict__ A, int64_t n, int64_t lda, int64_t sA,
+                                                             int64_t j0, T* __restrict__ wsL, int64_t npanels,
+                                                             int32_t* __restrict__ info, T* __restrict__ X, int64_t ldx,
+                                                             int64_t sX, int64_t nslab, int64_t nprow, int64_t nsyrk,
+                                                             int pre, int64_t wcols) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char panel_smem[];
+    int64_t blk = blockIdx.x;
+    const int64_t b = blockIdx.y;
+    if (blk < nslab) { panel_body2<T>(panel_smem, A, n, lda, sA, j0, wsL, npanels, info, blk, b, pre != 0); return; }
+    blk -= nslab;
+    if (blk < nprow) { prow_body<T>(panel_smem, A, n, lda, sA, j0, X, ldx, sX, blk, b, pre != 0); return; }
+    blk -= nprow;
+    if (blk < nsyrk) { syrk_body<T>(panel_smem, A, n, lda, sA, j0 - NB, j0 + NB, wcols, blk, b); return; }
+    blk -= nsyrk;
+    const int64_t nchunk = j0 / NB;                      // chunks 0 .. j - 1 carry the update of panel j - 1
+    pupd_body<T>(panel_smem, A, lda, sA, X, ldx, sX, j0 - NB, j0 + NB + (blk / nchunk) * NB, (blk % nchunk) * NB, b);
+}
+
 // LAST, ragged panel (nb < 64, nothing below it), factored in LDS by one wave.
 template <typename T>
 __global__ __launch_bounds__(64) void potrf_tail_kernel(T* __restrict__ A, int64_t n, int64_t lda, int64_t sA,
@@ -949,6 +1215,37 @@ int trtri_impl(const T* L, int64_t n, int64_t ldl, int64_t sL, T* X, int64_t ldx
     return nsgp_launch_status();
 }
 
+// Factor + inverse with the inverse accumulated inside the panel launches (n a multiple of 64, at most 2048: one level).
+template <typename T>
+int potrf_inv_impl(T* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int32_t* info, T* X, int64_t ldx, int64_t sX,
+                   void* ws, size_t wsb, void* stream) {
+    const int64_t npanels = n / NB;
+    const size_t need = (size_t)batch * npanels * NB * NB * sizeof(T);
+    if (!ws || wsb < need) return -11;
+    if (batch > 65535) return -5;
+    T* wsL = (T*)ws;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t step_lds = (4 * (size_t)NB * LDD + 4 * SB * LDI + NB) * sizeof(T);
+    nsgp_opt_in_lds((const void*)potrf_inv_step_kernel<T>, step_lds);
+    for (int64_t j0 = 0; j0 < n; j0 += NB) {
+        const int pre = j0 > 0;
+        const int64_t below = n - j0 - NB;
+        const int64_t nslab = below > 0 ? below / NB : 1;
+        const int64_t nprow = j0 / NB + 1;
+        const int64_t wcols = pre ? below : 0;
+        int64_t nsyrk = 0, npupd = 0;
+        if (pre && below > 0) {
+            const int64_t tn = below / NB;
+            nsyrk = tn * (tn + 1) / 2;
+            npupd = tn * (j0 / NB);
+        }
+        hipLaunchKernelGGL((potrf_inv_step_kernel<T>), dim3((unsigned)(nslab + nprow + nsyrk + npupd), (unsigned)batch),
+                           dim3(256), step_lds, st, A, n, lda, sA, j0, wsL, npanels, info, X, ldx, sX, nslab, nprow, nsyrk,
+                           pre, wcols);
+    }
+    return nsgp_launch_status();
+}
+
 // Cholesky factor and its inverse in one call: X = chol(A)^-1 (lower), A is overwritten with intermediate data (its strictly
 // lower part holds L21; the diagonal blocks and the upper triangle are NOT a valid factor).  Saves the write-back pass of
 // the factor (potrf_finalize_kernel: one launch, 2 n^2 elements of traffic) on the DSVI whitening chain, which only needs
@@ -961,6 +1258,9 @@ int potrf_trtri_impl(T* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, in
     const size_t w1 = (size_t)batch * cdiv64(n, NB) * NB * NB * sizeof(T);
     const size_t w2 = n > NB ? (size_t)batch * n * n * sizeof(T) : 0;
     if (!ws || wsb < w1 + w2) return -11;
+    const char* inve = getenv("NSGP_POTRF_INV");                     // A/B switch: 0 = factor, then the recursive inverse
+    if (n % NB == 0 && n <= 2048 && !(inve && inve[0] == '0'))
+        return potrf_inv_impl<T>(A, n, lda, sA, batch, info, X, ldx, sX, ws, w1, stream);
     int rc = potrf_impl<T>(A, n, lda, sA, batch, info, ws, w1, stream, false);
     if (rc) return rc;
     return trtri_impl<T>(A, n, lda, sA, X, ldx, sX, batch, (char*)ws + w1, w2, stream, (const T*)ws);

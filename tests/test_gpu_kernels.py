@@ -645,10 +645,12 @@ def test_gemm_narrow_tiles_for_single_round_triangular_launches(ops, N, ta, flag
 
 
 @pytest.mark.parametrize('dt', [F32, F64])
-@pytest.mark.parametrize('n,batch', [(64, 1), (200, 2), (1024, 3), (1100, 1)])
-def test_potrf_trtri_fused_equals_potrf_then_trtri(ops, dt, n, batch):
-    """nsgp_potrf_trtri (the whitening chain's entry: no write-back of the factor) == potrf followed by trtri, bit for bit
-    on the lower triangle; info is reported as by potrf (LAPACK convention), including a failing leading minor."""
+@pytest.mark.parametrize('n,batch', [(64, 1), (128, 2), (200, 2), (1024, 3), (1100, 1), (2048, 1)])
+def test_potrf_trtri_fused_equals_potrf_then_trtri(ops, dt, n, batch, monkeypatch):
+    """nsgp_potrf_trtri (the whitening chain's entry).  n a multiple of 64 up to 2048: the inverse is accumulated inside
+    the factorisation's panel launches (row-block solves + rank-64 updates of W, no separate inverse) -- equal to potrf
+    followed by trtri to round-off, strict upper triangle exactly zero; other sizes (and NSGP_POTRF_INV=0): potrf without
+    the write-back pass + the recursive inverse, bit for bit the two-call result.  info as by potrf (LAPACK convention)."""
     g = _g(60 + n)
     A = torch.randn(batch, n, n, generator=g, dtype=torch.float64)
     K = (A @ A.transpose(-1, -2) / n + torch.eye(n, dtype=torch.float64)).to(dt).cuda()
@@ -656,7 +658,17 @@ def test_potrf_trtri_fused_equals_potrf_then_trtri(ops, dt, n, batch):
     X0 = ops.trtri(L)
     X1, info1 = ops.potrf_trtri_(K.clone())
     assert info0.tolist() == [0] * batch and info1.tolist() == [0] * batch
-    assert torch.equal(torch.tril(X1), torch.tril(X0))
+    tol = 1e-13 if dt == F64 else 2e-5
+    assert float((torch.tril(X1) - torch.tril(X0)).abs().max() / X0.abs().max()) < tol
+    if n % 64 == 0:
+        assert bool((torch.triu(X1, 1) == 0).all())
+    eye = torch.eye(n, dtype=torch.float64)
+    res = (torch.tril(X1).cpu().double() @ torch.tril(L).cpu().double() - eye).abs().max()
+    assert float(res) < (1e-11 if dt == F64 else 2e-3)
+    monkeypatch.setenv('NSGP_POTRF_INV', '0')
+    X2, _ = ops.potrf_trtri_(K.clone())
+    assert torch.equal(torch.tril(X2), torch.tril(X0))
+    monkeypatch.delenv('NSGP_POTRF_INV')
     bad = K.clone()
     bad[0, 5, 5] = -1.0
     _, info2 = ops.potrf_trtri_(bad)
