@@ -198,6 +198,11 @@ int nsgp_potrf_trtri_f32(float* A, int64_t n, int64_t lda, int64_t sA, int64_t b
                          int64_t ldx, int64_t sX, void* ws, size_t ws_bytes, void* stream);
 int nsgp_potrf_trtri_f64(double* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int32_t* info, double* X,
                          int64_t ldx, int64_t sX, void* ws, size_t ws_bytes, void* stream);
+/* the float64 chain of a float32 model: X32 (same leading dimension and batch stride, in elements) receives a float32 copy
+ * of X from the same launches when the in-launch inverse runs (n a multiple of 64, n <= 2048); *wrote32 (host int) says
+ * whether it did -- otherwise the caller casts X itself */
+int nsgp_potrf_trtri_f64_w32(double* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int32_t* info, double* X,
+                             int64_t ldx, int64_t sX, float* X32, int* wrote32, void* ws, size_t ws_bytes, void* stream);
 int nsgp_trtri_f32(const float* L, int64_t n, int64_t ldl, int64_t sL, float* X, int64_t ldx,
                    int64_t sX, int64_t batch, void* ws, size_t ws_bytes, void* stream);
 int nsgp_trtri_f64(const double* L, int64_t n, int64_t ldl, int64_t sL, double* X, int64_t ldx,

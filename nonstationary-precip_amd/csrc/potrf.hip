@@ -741,7 +741,9 @@ __device__ __forceinline__ void prow_subst_step(T* Rc, const T* S, const T* Dinv
 template <typename T>
 __device__ __forceinline__ void prow_body(unsigned char* panel_smem, const T* __restrict__ A, int64_t n, int64_t lda,
                                           int64_t sA, int64_t j0, T* __restrict__ X, int64_t ldx, int64_t sX, int64_t c,
-                                          int64_t b, bool pre) {
+                                          int64_t b, bool pre, float* __restrict__ X32) {
+    // X32 != null (float64 chain of a float32 model): a float32 copy of W (same leading dimension / batch stride in
+    // elements) is written along with it -- the cast pass the layers would otherwise launch
     typedef Mma16<T> MM;
     typedef typename MM::acc_t acc_t;
     T* S = reinterpret_cast<T*>(panel_smem);            // [64][LDD]   diagonal block -> L11
@@ -760,7 +762,10 @@ __device__ __forceinline__ void prow_body(unsigned char* panel_smem, const T* __
     const int fm = lane & 15, fk = lane >> 4;
     if (diag) {                                          // zero the rest of these rows (W is lower triangular); off the
         for (int i = w; i < NB; i += 4)                  // critical path: this workgroup has no chunk to load
-            for (int64_t cc = j0 + NB + lane; cc < n; cc += 64) Xb[(j0 + i) * ldx + cc] = T(0);
+            for (int64_t cc = j0 + NB + lane; cc < n; cc += 64) {
+                Xb[(j0 + i) * ldx + cc] = T(0);
+                if (X32) X32[b * sX + (j0 + i) * ldx + cc] = 0.f;
+            }
     }
     {
         T dr[SB], xr[SB], pr[SB], qr[SB];
@@ -877,7 +882,11 @@ __device__ __forceinline__ void prow_body(unsigned char* panel_smem, const T* __
     prow_subst_step<T, 3>(Rs + w * SB, S, Dinv, lane);                    // last row block: every wave its column strip
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < SB; ++i) Xb[(j0 + w * SB + i) * ldx + c0 + lane] = Rs[(w * SB + i) * LDD + lane];
+    for (int i = 0; i < SB; ++i) {
+        const T v = Rs[(w * SB + i) * LDD + lane];
+        Xb[(j0 + w * SB + i) * ldx + c0 + lane] = v;
+        if (X32) X32[b * sX + (j0 + w * SB + i) * ldx + c0 + lane] = (float)v;
+    }
 }
 
 // W[i][c] -= L[i][j-1] W[j-1][c]  for one 64 x 64 tile (row block i >= j + 1 given by r0, chunk c0 <= j0 - 64); kp = j0 - 64.
@@ -937,13 +946,13 @@ __global__ __launch_bounds__(256) void potrf_inv_step_kernel(T* __restrict__ A, 
                                                              int64_t j0, T* __restrict__ wsL, int64_t npanels,
                                                              int32_t* __restrict__ info, T* __restrict__ X, int64_t ldx,
                                                              int64_t sX, int64_t nslab, int64_t nprow, int64_t nsyrk,
-                                                             int pre, int64_t wcols) {
+                                                             int pre, int64_t wcols, float* __restrict__ X32) {
     extern __shared__ __attribute__((aligned(16))) unsigned char panel_smem[];
     int64_t blk = blockIdx.x;
     const int64_t b = blockIdx.y;
     if (blk < nslab) { panel_body2<T>(panel_smem, A, n, lda, sA, j0, wsL, npanels, info, blk, b, pre != 0); return; }
     blk -= nslab;
-    if (blk < nprow) { prow_body<T>(panel_smem, A, n, lda, sA, j0, X, ldx, sX, blk, b, pre != 0); return; }
+    if (blk < nprow) { prow_body<T>(panel_smem, A, n, lda, sA, j0, X, ldx, sX, blk, b, pre != 0, X32); return; }
     blk -= nprow;
     if (blk < nsyrk) { syrk_body<T>(panel_smem, A, n, lda, sA, j0 - NB, j0 + NB, wcols, blk, b); return; }
     blk -= nsyrk;
@@ -1218,7 +1227,7 @@ int trtri_impl(const T* L, int64_t n, int64_t ldl, int64_t sL, T* X, int64_t ldx
 // Factor + inverse with the inverse accumulated inside the panel launches (n a multiple of 64, at most 2048: one level).
 template <typename T>
 int potrf_inv_impl(T* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int32_t* info, T* X, int64_t ldx, int64_t sX,
-                   void* ws, size_t wsb, void* stream) {
+                   void* ws, size_t wsb, void* stream, float* X32 = nullptr) {
     const int64_t npanels = n / NB;
     const size_t need = (size_t)batch * npanels * NB * NB * sizeof(T);
     if (!ws || wsb < need) return -11;
@@ -1241,7 +1250,7 @@ int potrf_inv_impl(T* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int3
         }
         hipLaunchKernelGGL((potrf_inv_step_kernel<T>), dim3((unsigned)(nslab + nprow + nsyrk + npupd), (unsigned)batch),
                            dim3(256), step_lds, st, A, n, lda, sA, j0, wsL, npanels, info, X, ldx, sX, nslab, nprow, nsyrk,
-                           pre, wcols);
+                           pre, wcols, X32);
     }
     return nsgp_launch_status();
 }
@@ -1252,15 +1261,18 @@ int potrf_inv_impl(T* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int3
 // the inverse.  ws: nsgp_potrf_workspace + nsgp_trtri_workspace bytes.
 template <typename T>
 int potrf_trtri_impl(T* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int32_t* info, T* X, int64_t ldx, int64_t sX,
-                     void* ws, size_t wsb, void* stream) {
+                     void* ws, size_t wsb, void* stream, float* X32 = nullptr, int* wrote32 = nullptr) {
     if (n < 0) return -2; if (batch < 0) return -5;
     if (n == 0 || batch == 0) return 0;
     const size_t w1 = (size_t)batch * cdiv64(n, NB) * NB * NB * sizeof(T);
     const size_t w2 = n > NB ? (size_t)batch * n * n * sizeof(T) : 0;
     if (!ws || wsb < w1 + w2) return -11;
     const char* inve = getenv("NSGP_POTRF_INV");                     // A/B switch: 0 = factor, then the recursive inverse
-    if (n % NB == 0 && n <= 2048 && !(inve && inve[0] == '0'))
-        return potrf_inv_impl<T>(A, n, lda, sA, batch, info, X, ldx, sX, ws, w1, stream);
+    if (wrote32) *wrote32 = 0;
+    if (n % NB == 0 && n <= 2048 && !(inve && inve[0] == '0')) {
+        if (wrote32 && X32) *wrote32 = 1;
+        return potrf_inv_impl<T>(A, n, lda, sA, batch, info, X, ldx, sX, ws, w1, stream, X32);
+    }
     int rc = potrf_impl<T>(A, n, lda, sA, batch, info, ws, w1, stream, false);
     if (rc) return rc;
     return trtri_impl<T>(A, n, lda, sA, X, ldx, sX, batch, (char*)ws + w1, w2, stream, (const T*)ws);
@@ -1293,6 +1305,10 @@ int nsgp_potrf_trtri_f32(float* A, int64_t n, int64_t lda, int64_t sA, int64_t b
 int nsgp_potrf_trtri_f64(double* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int32_t* info, double* X,
                          int64_t ldx, int64_t sX, void* ws, size_t wsb, void* stream) {
     return potrf_trtri_impl<double>(A, n, lda, sA, batch, info, X, ldx, sX, ws, wsb, stream);
+}
+int nsgp_potrf_trtri_f64_w32(double* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int32_t* info, double* X,
+                             int64_t ldx, int64_t sX, float* X32, int* wrote32, void* ws, size_t wsb, void* stream) {
+    return potrf_trtri_impl<double>(A, n, lda, sA, batch, info, X, ldx, sX, ws, wsb, stream, X32, wrote32);
 }
 int nsgp_trtri_f32(const float* L, int64_t n, int64_t ldl, int64_t sL, float* X, int64_t ldx, int64_t sX,
                    int64_t batch, void* ws, size_t wsb, void* stream) {

@@ -452,9 +452,11 @@ def trtri(L):
     return X
 
 
-def potrf_trtri_(A):
+def potrf_trtri_(A, want_f32=False):
     """(X, info) with X = chol(A)^-1 (lower triangular) for a contiguous (batched) SPD matrix that is CONSUMED: on return A
-    holds intermediate data, not a factor.  One chain of launches without the factor's write-back pass."""
+    holds intermediate data, not a factor.  One chain of launches without the factor's write-back pass.
+    want_f32=True (float64 A): returns (X, info, X32) with a float32 copy of X -- written by the same launches when the
+    in-launch inverse runs, by a cast otherwise."""
     ref = _chk(A)
     if A.dim() not in (2, 3) or A.shape[-1] != A.shape[-2] or not A.is_contiguous():
         raise BackendError('potrf_trtri_: contiguous square (batched) matrix expected')
@@ -465,8 +467,19 @@ def potrf_trtri_(A):
     lib = _lib.load()
     ws = _ws(lib.nsgp_potrf_workspace(n, batch, ref.element_size()) + lib.nsgp_trtri_workspace(n, batch, ref.element_size()),
              ref.device)
+    if want_f32 and ref.dtype == torch.float64:
+        import ctypes
+        X32 = torch.empty(A.shape, dtype=torch.float32, device=ref.device)
+        wrote = ctypes.c_int(0)
+        _lib.call('nsgp_potrf_trtri_f64_w32', _p(A), n, n, n * n, batch, _p(info), _p(X), n, n * n, _p(X32),
+                  ctypes.addressof(wrote), _p(ws), ws.numel(), _stream())
+        if not wrote.value:
+            X32 = cast(X, torch.float32)
+        return X, info, X32
     _lib.call(f'nsgp_potrf_trtri_{_sfx(ref)}', _p(A), n, n, n * n, batch, _p(info), _p(X), n, n * n, _p(ws), ws.numel(),
               _stream())
+    if want_f32:
+        return X, info, (X if ref.dtype == torch.float32 else cast(X, torch.float32))
     return X, info
 
 

@@ -55,7 +55,11 @@ class WhitenFn(torch.autograd.Function):
             z64.append((Zd, lsd, osd))
             ops.rbf_build(Zd, Zd, lsd, osd, diag_add=jitter, out=K[off:off + Z.shape[0]])
             off += Z.shape[0]
-        W64, info = ops.potrf_trtri_(K)          # K is consumed; the factor itself is never needed
+        # K is consumed; the factor itself is never needed.  A float32 model also gets its float32 W from the same launches
+        if out_dtype == torch.float32:
+            W64, info, W32 = ops.potrf_trtri_(K, want_f32=True)
+        else:
+            (W64, info), W32 = ops.potrf_trtri_(K), None
         ctx.save_for_backward(W64, *[t for g in z64 for t in g])
         ctx.sizes = [g[0].shape[0] for g in groups]
         ctx.dtypes = [g[0].dtype for g in groups]
@@ -63,7 +67,7 @@ class WhitenFn(torch.autograd.Function):
         ctx.mark_non_differentiable(info)
         ctx.set_materialize_grads(False)         # no zero-fill launches for outputs nobody differentiated
         # the layers consume W in their own dtype: ONE cast of the batched result here instead of one per layer
-        Wout = W64 if out_dtype in (None, torch.float64) else ops.cast(W64, out_dtype)
+        Wout = W64 if out_dtype in (None, torch.float64) else (W32 if W32 is not None else ops.cast(W64, out_dtype))
         outs, outs64, off = [], [], 0
         for b in ctx.sizes:                      # one output per group (views of the batched result)
             outs.append(Wout[off:off + b])
