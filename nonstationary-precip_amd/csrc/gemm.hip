@@ -591,7 +591,14 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || N
             // (waves of a diagonal output tile of a lower-only product take the hot loop too and compute their whole 64 x 64
             // block: sending them through the one-tile-ahead generic loop to skip the MFMA tiles above the diagonal held
             // back the whole workgroup -- Wbar = tril(Abar Kzx^T): 482 -> 456 us)
-            if (EDGE == 0) {
+            // EDGE = 1 (ragged or unaligned launch): a workgroup whose tile lies inside M and N, on 16-byte aligned
+            // operands, still runs its whole K-tiles through the hot loop; only the ragged last K-tile and the boundary
+            // workgroups pay for the bounds code (n = 40000 instead of 40960 used to halve the rate of every launch)
+            // (not for the k-contiguous x k-contiguous variants -- the long-K split products: with the bounds code next to it
+            // their hot loop spills, 1365 -> 1485 us at M = 1000, n = 40000)
+            const bool interior = EDGE == 0 || (!(MODE_A == 0 && MODE_B == 0) && g.vecA && g.vecB && m0 + BM <= g.M &&
+                                                n0 + BN <= g.N);
+            if (interior) {
                 while (r0 < nt && !regular(r0)) ++r0;
                 r1 = r0;
                 while (r1 < nt && regular(r1)) ++r1;
