@@ -141,11 +141,49 @@ constexpr int LDI = SB + 1;
 // Sub-panel step of the 64x64 diagonal block held in LDS (S, leading dimension LDD): ONE wave takes
 // columns [c0, c0+16) with row `lane` in registers, factors them (16 pivots, v_readlane broadcasts),
 // and writes them back.  Lanes < c0 write zeros (upper part of L).
-template <typename T, int C0> __device__ __forceinline__ int factor_subpanel(T* S, T* rd, int lane) {
+#ifndef NSGP_POTRF_LDSCOL
+#define NSGP_POTRF_LDSCOL 1
+#endif
+template <typename T, int C0> __device__ __forceinline__ int factor_subpanel(T* S, T* rd, T* cb, int lane) {
     T a[SB];
 #pragma unroll
     for (int j = 0; j < SB; ++j) a[j] = S[lane * LDD + C0 + j];
     int bad = 0;
+#if NSGP_POTRF_LDSCOL
+    // The wave is bound by instruction issue, and 2/5 of its instructions were v_readlane pairs (one pair per rank-1 update
+    // a[j] -= l_k[row] * l_k[C0 + j], the multiplier broadcast from lane C0 + j through an SGPR pair -- plus v_writelane spills
+    // of those SGPRs).  Here only the update the NEXT pivot waits for (j = k + 1) takes that route; the pivot column's
+    // other 15 - k multipliers go through LDS: lanes C0 .. C0 + 15 publish l_k[lane], every lane reads l_k[C0 + j] back
+    // with ONE broadcast ds_read_b64 per j (the LDS serves a wave's requests in order, so the reads see the write), and
+    // the updates are applied one pivot later, when the data has long arrived (cb: two buffers of 16).
+    T pend[SB];                                          // multipliers of the previous pivot, read one iteration ago
+    T lprev = T(0);
+#pragma unroll
+    for (int k = 0; k < SB; ++k) {
+        const int p = C0 + k;
+        const T akk = bcast(a[k], p);
+        if (!(akk > T(0)) && bad == 0) bad = p + 1;
+        const T inv = fast_rsqrt(akk);
+        const T piv = akk * inv;
+        if (lane == 0) rd[p] = inv;                                          // 1 / L[p][p]
+        const T lik = lane == p ? piv : (lane > p ? a[k] * inv : T(0));
+        a[k] = lik;
+        if (k + 1 < SB) {
+            if (lane >= C0 && lane < C0 + SB) cb[(k & 1) * SB + (lane - C0)] = lik;
+            a[k + 1] -= lik * bcast(lik, C0 + k + 1);                        // the next pivot's column: no LDS round trip
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");          // compiler ordering: the write is issued before the reads
+        }
+        if (k > 0) {                                                         // pivot k - 1's other updates (data is here)
+#pragma unroll
+            for (int j = k + 1; j < SB; ++j) a[j] -= lprev * pend[j];
+        }
+        if (k + 2 < SB) {
+#pragma unroll
+            for (int j = k + 2; j < SB; ++j) pend[j] = cb[(k & 1) * SB + j];
+        }
+        lprev = lik;
+    }
+#else
 #pragma unroll
     for (int k = 0; k < SB; ++k) {
         const int p = C0 + k;
@@ -159,6 +197,7 @@ template <typename T, int C0> __device__ __forceinline__ int factor_subpanel(T* 
 #pragma unroll
         for (int j = k + 1; j < SB; ++j) a[j] -= lik * bcast(lik, C0 + j);
     }
+#endif
 #pragma unroll
     for (int j = 0; j < SB; ++j) S[lane * LDD + C0 + j] = a[j];
     return bad;
@@ -271,7 +310,7 @@ __device__ __forceinline__ void panel_body(unsigned char* panel_smem, T* __restr
 #define NSGP_SUBPANEL(C0)                                                                             \
     {                                                                                                 \
         constexpr int B0 = C0 / SB;                                                                   \
-        if (w == 0) { const int bd = factor_subpanel<T, C0>(S, rd, lane); if (bad == 0) bad = bd; }   \
+        if (w == 0) { const int bd = factor_subpanel<T, C0>(S, rd, Qs + NB * LDD, lane); if (bad == 0) bad = bd; }   \
         else if (w == 1 && B0 > 0) invert_subblock<T>(S, rd, Dinv, B0 - 1, lane);  /* overlaps the factor */ \
         __syncthreads();                                                                              \
         constexpr int NT = (3 - B0) * (4 - B0) / 2;      /* lower tiles of the trailing block */      \
@@ -487,7 +526,7 @@ __device__ __forceinline__ void panel_body2(unsigned char* panel_smem, T* __rest
     const bool slab = rows > 0;
     int bad = 0;
     // ---- F0 ----
-    if (w == 0) { const int bd = factor_subpanel<T, 0>(S, rd, lane); if (bad == 0) bad = bd; }
+    if (w == 0) { const int bd = factor_subpanel<T, 0>(S, rd, Qs + NB * LDD, lane); if (bad == 0) bad = bd; }
     else if (pre) {
         for (int q = w - 1; q < 12; q += 3) {            // (row block, column tile 1..3) of S -= P P^T
             const int rb = q / 3, t = 1 + q % 3;
@@ -518,7 +557,7 @@ __device__ __forceinline__ void panel_body2(unsigned char* panel_smem, T* __rest
     }
     NSGP_TRAIL(0)
     // ---- F1 ----
-    if (w == 0) { const int bd = factor_subpanel<T, 16>(S, rd, lane); if (bad == 0) bad = bd; }
+    if (w == 0) { const int bd = factor_subpanel<T, 16>(S, rd, Qs + NB * LDD, lane); if (bad == 0) bad = bd; }
     else {
         // X -= Q P^T, 16 (strip, column tile) tasks over F1 and F2: column tiles 0 and 1 now (waves 2, 3: the substitution
         // needs them first), tile 2 by wave 1 behind its inversions, tile 3 in F2
@@ -535,7 +574,7 @@ __device__ __forceinline__ void panel_body2(unsigned char* panel_smem, T* __rest
     __syncthreads();
     NSGP_TRAIL(16)
     // ---- F2 ----
-    if (w == 0) { const int bd = factor_subpanel<T, 32>(S, rd, lane); if (bad == 0) bad = bd; }
+    if (w == 0) { const int bd = factor_subpanel<T, 32>(S, rd, Qs + NB * LDD, lane); if (bad == 0) bad = bd; }
     else {
         auto xtile = [&](int rb, int t) __attribute__((always_inline)) {
             rank64_tile<T>(Xs + (rb * SB) * LDD + t * SB, Qs + (rb * SB) * LDD, Ps + (t * SB) * LDD, lane);
@@ -552,7 +591,7 @@ __device__ __forceinline__ void panel_body2(unsigned char* panel_smem, T* __rest
     __syncthreads();
     NSGP_TRAIL(32)
     // ---- F3 ----
-    if (w == 0) { const int bd = factor_subpanel<T, 48>(S, rd, lane); if (bad == 0) bad = bd; }
+    if (w == 0) { const int bd = factor_subpanel<T, 48>(S, rd, Qs + NB * LDD, lane); if (bad == 0) bad = bd; }
     else if (w == 1) invert_subblock<T>(S, rd, Dinv, 2, lane);
     else if (slab) {
         slab_subst_step<T, 1>(Xs + ((w - 2) * SB) * LDD, S, Dinv, lane);
@@ -807,7 +846,7 @@ __device__ __forceinline__ void prow_body(unsigned char* panel_smem, const T* __
         __syncthreads();
     }
     // ---- F0 ----
-    if (w == 0) (void)factor_subpanel<T, 0>(S, rd, lane);
+    if (w == 0) (void)factor_subpanel<T, 0>(S, rd, Qs + NB * LDD, lane);
     else if (pre) {
         for (int q = w - 1; q < 12; q += 3) {
             const int rb = q / 3, t = 1 + q % 3;
@@ -843,7 +882,7 @@ __device__ __forceinline__ void prow_body(unsigned char* panel_smem, const T* __
     };
     // ---- F1 ----  (the substitution walks row blocks 0, 1, 2, 3 of EVERY column strip: all column tiles of row blocks 0
     // and 1 first)
-    if (w == 0) (void)factor_subpanel<T, 16>(S, rd, lane);
+    if (w == 0) (void)factor_subpanel<T, 16>(S, rd, Qs + NB * LDD, lane);
     else if (w == 1) {
         invert_subblock<T>(S, rd, Dinv, 0, lane);
         if (upd) { rtile(2, 0); rtile(2, 1); }
@@ -853,7 +892,7 @@ __device__ __forceinline__ void prow_body(unsigned char* panel_smem, const T* __
     __syncthreads();
     NSGP_TRAIL(16)
     // ---- F2 ----
-    if (w == 0) (void)factor_subpanel<T, 32>(S, rd, lane);
+    if (w == 0) (void)factor_subpanel<T, 32>(S, rd, Qs + NB * LDD, lane);
     else if (w == 1) {
         invert_subblock<T>(S, rd, Dinv, 1, lane);
         if (upd) { rtile(2, 2); rtile(2, 3); }
@@ -865,7 +904,7 @@ __device__ __forceinline__ void prow_body(unsigned char* panel_smem, const T* __
     __syncthreads();
     NSGP_TRAIL(32)
     // ---- F3 ----
-    if (w == 0) (void)factor_subpanel<T, 48>(S, rd, lane);
+    if (w == 0) (void)factor_subpanel<T, 48>(S, rd, Qs + NB * LDD, lane);
     else if (w == 1) invert_subblock<T>(S, rd, Dinv, 2, lane);
     else {
         prow_subst_step<T, 1>(Rs + (w - 2) * SB, S, Dinv, lane);
@@ -1020,7 +1059,7 @@ int potrf_impl(T* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int32_t*
     if (batch > 65535) return -5;
     T* wsL = (T*)ws;
     hipStream_t st = (hipStream_t)stream;
-    const size_t step_lds = (4 * (size_t)NB * LDD + 4 * SB * LDI + NB) * sizeof(T);
+    const size_t step_lds = (4 * (size_t)NB * LDD + 4 * SB * LDI + NB + 2 * SB) * sizeof(T);   // + the pivot-column exchange buffers
     nsgp_opt_in_lds((const void*)potrf_step_kernel<T>, step_lds);
     // Two-level blocking for large matrices: rank-64 updates stay inside an outer panel of NB2 columns (they are
     // HBM-bound: 8 flop/B in float64), the rest of the trailing matrix is updated once per outer panel with
@@ -1234,7 +1273,7 @@ int potrf_inv_impl(T* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int3
     if (batch > 65535) return -5;
     T* wsL = (T*)ws;
     hipStream_t st = (hipStream_t)stream;
-    const size_t step_lds = (4 * (size_t)NB * LDD + 4 * SB * LDI + NB) * sizeof(T);
+    const size_t step_lds = (4 * (size_t)NB * LDD + 4 * SB * LDI + NB + 2 * SB) * sizeof(T);   // + the pivot-column exchange buffers
     nsgp_opt_in_lds((const void*)potrf_inv_step_kernel<T>, step_lds);
     for (int64_t j0 = 0; j0 < n; j0 += NB) {
         const int pre = j0 > 0;
