@@ -158,6 +158,14 @@ template <typename T, int C0> __device__ __forceinline__ int factor_subpanel(T* 
     // the updates are applied one pivot later, when the data has long arrived (cb: two buffers of 16).
     T pend[SB];                                          // multipliers of the previous pivot, read one iteration ago
     T lprev = T(0);
+    // addresses once per sub-panel, in VGPRs: the publishing lanes' slot, and a (uniform) read base that the compiler keeps
+    // in a VGPR so that every read is base + immediate (it re-materialised an SGPR address per read: 10 of 53
+    // instructions per pivot)
+    const int pub = lane - C0;
+    const bool is_pub = (unsigned)pub < (unsigned)SB;
+    int wo = is_pub ? pub : 0, ro = lane & 0;            // element offsets pinned in VGPRs (the pointers stay LDS pointers)
+    asm volatile("" : "+v"(wo), "+v"(ro));
+    T rdv = T(0);                                        // lane k of the publishing lanes keeps 1 / L[p][p] of pivot k
 #pragma unroll
     for (int k = 0; k < SB; ++k) {
         const int p = C0 + k;
@@ -165,11 +173,11 @@ template <typename T, int C0> __device__ __forceinline__ int factor_subpanel(T* 
         if (!(akk > T(0)) && bad == 0) bad = p + 1;
         const T inv = fast_rsqrt(akk);
         const T piv = akk * inv;
-        if (lane == 0) rd[p] = inv;                                          // 1 / L[p][p]
+        rdv = lane == p ? inv : rdv;
         const T lik = lane == p ? piv : (lane > p ? a[k] * inv : T(0));
         a[k] = lik;
         if (k + 1 < SB) {
-            if (lane >= C0 && lane < C0 + SB) cb[(k & 1) * SB + (lane - C0)] = lik;
+            if (is_pub) cb[wo + (k & 1) * SB] = lik;
             a[k + 1] -= lik * bcast(lik, C0 + k + 1);                        // the next pivot's column: no LDS round trip
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");          // compiler ordering: the write is issued before the reads
         }
@@ -179,10 +187,11 @@ template <typename T, int C0> __device__ __forceinline__ int factor_subpanel(T* 
         }
         if (k + 2 < SB) {
 #pragma unroll
-            for (int j = k + 2; j < SB; ++j) pend[j] = cb[(k & 1) * SB + j];
+            for (int j = k + 2; j < SB; ++j) pend[j] = cb[ro + (k & 1) * SB + j];
         }
         lprev = lik;
     }
+    if (is_pub) rd[lane] = rdv;                                              // 1 / L[p][p], one store for the sub-panel
 #else
 #pragma unroll
     for (int k = 0; k < SB; ++k) {
