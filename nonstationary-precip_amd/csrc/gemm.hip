@@ -70,6 +70,7 @@ struct GemmArgs {
     int part_rows;                // EPI 1: tile rows per batch element in the partial buffers (>= tiles_m; 0 = tiles_m)
     int xcd_chunk;                // > 0: chunked XCD placement of a split-K launch, workgroups per XCD (see the kernel)
     int xcd_group;                // > 0: XCD-aware tile order with this many tile rows per group (see the kernel)
+    int batch_perm;               // 1: single-round batched launch -- permute the tile order per batch element (see the kernel)
     int vecA, vecB;               // 16-byte vector global loads allowed for A / B
     int modeA, modeB;             // 0: contiguous along k, 1: contiguous along m (n)
 };
@@ -216,6 +217,17 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || N
     // cost every workgroup ~1 us of scalar code before its first load.
     const int tiles_m = (int)g.tiles_m, tiles_n = (int)g.tiles_n;
     int tid_lin = (int)blockIdx.x, zz = (int)blockIdx.y;
+    if (g.batch_perm) {
+        // A launch whose workgroups are all resident at once places workgroup i of EVERY batch element on the same CU
+        // (ids i, i + n, i + 2n are dealt to the same XCD and CU in turn), so with a triangular operand a CU gets the
+        // longest tile of each matrix and another the shortest of each: the launch takes as long as that one CU (Cholesky
+        // adjoint, 3 x 1024^2: 3 x 64 K-tiles on one CU against a mean of 70).  Odd batch elements walk the tiles backwards
+        // and every second pair starts half way round, so a CU's tiles have complementary lengths.  Speed only.
+        const int ntile = (int)gridDim.x;
+        int t = tid_lin + ((zz >> 1) & 1) * (ntile >> 1);
+        if (t >= ntile) t -= ntile;
+        tid_lin = (zz & 1) ? ntile - 1 - t : t;
+    }
     if (g.xcd_chunk > 0) {
         // Long-K products with a small output (Lqbar = A diag(v) C^T, Wbar = Abar Kzx^T; split along K into slabs): every
         // (tile, slice) workgroup streams a 128-row panel of both operands once, and the tiles of one slice read the SAME
@@ -930,6 +942,7 @@ int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam,
     int64_t ngrid_x = ngrid, ngrid_y = nb * g.ksplit;
     g.xcd_group = 0;
     g.xcd_chunk = 0;
+    g.batch_perm = 0;
     g.part_rows = epi ? epi->part_rows : 0;
     g.nbk = (int)(nb * g.ksplit);
     const char* no_xcd = getenv("NSGP_GEMM_NO_XCD");              // A/B switches for tools/gemm_bench.py
@@ -953,6 +966,12 @@ int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam,
         g.xcd_chunk = (int)cdiv64(total, 8);
         // the launch keeps its (tiles, batch x slices) shape; workgroups past `total` after the remap exit at once
         ngrid_y = cdiv64(8 * (int64_t)g.xcd_chunk, ngrid);
+    } else if (g.ksplit == 1 && nb > 1 && (flags & (NSGP_GEMM_A_LOWER | NSGP_GEMM_A_UPPER | NSGP_GEMM_B_LOWER |
+                                                     NSGP_GEMM_B_UPPER | NSGP_GEMM_C_LOWER))) {
+        // batched triangular launch that fits one round of resident workgroups: complementary tile orders per batch element
+        const int64_t slots = 256 * (p.big ? (p.narrow ? 3 : 2) : (sizeof(T) == 4 ? 6 : 3));
+        const char* bpe = getenv("NSGP_GEMM_BATCH_PERM");            // A/B switch (default on)
+        if (ngrid * ngrid_y <= slots && !(bpe && bpe[0] == '0')) g.batch_perm = 1;
     }
     dim3 grid((unsigned)ngrid_x, (unsigned)ngrid_y, 1);
     Epi ep{};
