@@ -227,6 +227,13 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || N
         int t = tid_lin + ((zz >> 1) & 1) * (ntile >> 1);
         if (t >= ntile) t -= ntile;
         tid_lin = (zz & 1) ? ntile - 1 - t : t;
+        if (g.batch_perm == 2) {
+            // more than one round: batch element fastest, so that the longest-first tile order holds across the whole launch
+            // (with the batch on grid.y the second matrix's long tiles queued behind the first one's short ones)
+            const int lin = zz * ntile + (int)blockIdx.x;
+            tid_lin = lin / g.nbk;
+            zz = lin % g.nbk;
+        }
     }
     if (g.xcd_chunk > 0) {
         // Long-K products with a small output (Lqbar = A diag(v) C^T, Wbar = Abar Kzx^T; split along K into slabs): every
@@ -971,7 +978,8 @@ int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam,
         // batched triangular launch that fits one round of resident workgroups: complementary tile orders per batch element
         const int64_t slots = 256 * (p.big ? (p.narrow ? 3 : 2) : (sizeof(T) == 4 ? 6 : 3));
         const char* bpe = getenv("NSGP_GEMM_BATCH_PERM");            // A/B switch (default on)
-        if (ngrid * ngrid_y <= slots && !(bpe && bpe[0] == '0')) g.batch_perm = 1;
+        // (more rounds: batch element fastest -- hidden layer, n = 4096 x 2 GPs: 234 -> 225 us for the forward pair)
+        if (!(bpe && bpe[0] == '0')) g.batch_perm = (ngrid * ngrid_y <= slots) ? 1 : ((bpe && bpe[0] == '1') ? 0 : 2);
     }
     dim3 grid((unsigned)ngrid_x, (unsigned)ngrid_y, 1);
     Epi ep{};
@@ -1130,6 +1138,11 @@ int tri_gemm_colstats_f64acc_impl(const double* W, const float* X, const float* 
     g.vecA = (M % 4 == 0) && ((uintptr_t)W % 32 == 0);
     g.vecB = kg ? 1 : ((n % 4 == 0) && ((uintptr_t)X % 16 == 0));
     if (g.tiles_m * g.tiles_n > 2147483647LL || batch > 65535) return -24;
+    if (batch > 1) {                                     // tile order across the batch, as in gemm_impl
+        const char* bpe = getenv("NSGP_GEMM_BATCH_PERM");
+        if (!(bpe && bpe[0] == '0'))
+            g.batch_perm = (g.tiles_m * g.tiles_n * batch <= 512) ? 1 : 0;   // (batch-fastest measured slower here: 314 -> 329 us)
+    }
     Epi ep{};
     ep.kind = 1; ep.rv = rowvec; ep.p0 = part_dot; ep.p1 = part_sq; ep.modeA = 0; ep.modeB = 1;
     if (kg) {
