@@ -217,7 +217,18 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || N
     // cost every workgroup ~1 us of scalar code before its first load.
     const int tiles_m = (int)g.tiles_m, tiles_n = (int)g.tiles_n;
     int tid_lin = (int)blockIdx.x, zz = (int)blockIdx.y;
-    if (g.batch_perm) {
+    if (g.batch_perm == 3) {
+        // one matrix, one round: workgroups i, i + 256, i + 512 share a CU (ids are dealt to the 256 CUs in turn) and the
+        // tile order is longest-first, so CU 0 got the longest tile of every block of 256.  Every second block of 256 runs
+        // backwards (snake): a CU's tiles have complementary lengths.  Speed only.
+        const int ntile = (int)gridDim.x;
+        const int blk = tid_lin >> 8;
+        if (blk & 1) {
+            const int base = blk << 8;
+            const int top = base + 255 < ntile - 1 ? base + 255 : ntile - 1;
+            tid_lin = base + (top - tid_lin);
+        }
+    } else if (g.batch_perm) {
         // A launch whose workgroups are all resident at once places workgroup i of EVERY batch element on the same CU
         // (ids i, i + n, i + 2n are dealt to the same XCD and CU in turn), so with a triangular operand a CU gets the
         // longest tile of each matrix and another the shortest of each: the launch takes as long as that one CU (Cholesky
@@ -980,6 +991,11 @@ int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam,
         const char* bpe = getenv("NSGP_GEMM_BATCH_PERM");            // A/B switch (default on)
         // (more rounds: batch element fastest -- hidden layer, n = 4096 x 2 GPs: 234 -> 225 us for the forward pair)
         if (!(bpe && bpe[0] == '0')) g.batch_perm = (ngrid * ngrid_y <= slots) ? 1 : ((bpe && bpe[0] == '1') ? 0 : 2);
+    } else if (g.ksplit == 1 && nb == 1 && (flags & (NSGP_GEMM_A_LOWER | NSGP_GEMM_A_UPPER | NSGP_GEMM_B_LOWER |
+                                                      NSGP_GEMM_B_UPPER | NSGP_GEMM_C_LOWER))) {
+        const int64_t slots = 256 * (p.big ? (p.narrow ? 3 : 2) : (sizeof(T) == 4 ? 6 : 3));
+        const char* bpe = getenv("NSGP_GEMM_BATCH_PERM");
+        if (ngrid > 256 && ngrid <= slots && !(bpe && bpe[0] == '0')) g.batch_perm = 3;       // snake (see the kernel)
     }
     dim3 grid((unsigned)ngrid_x, (unsigned)ngrid_y, 1);
     Epi ep{};
