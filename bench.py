@@ -517,6 +517,7 @@ def main():
         opt.step(gather=False)
 
     held = {}
+    staged_graph_error = None
 
     def stage_group_fn(gi):
         # exchange group gi of the staged backward: group 0 = forward + ELBO + the loss's own backward stage
@@ -564,9 +565,15 @@ def main():
             p0 = opt.bucket.flat_p.detach().clone()      # graph warm-up / capture runs real steps: undo them below
             if staged:
                 from nsgp.graph import GraphedSequence
-                g_seq = GraphedSequence([stage_group_fn(gi) for gi in range(groups['n'])],
-                                        [exchange_fn(gi) for gi in range(groups['n'])])
-                g_adam = GraphedCallable(adam_step, warmup=1)
+                try:
+                    g_seq = GraphedSequence([stage_group_fn(gi) for gi in range(groups['n'])],
+                                            [exchange_fn(gi) for gi in range(groups['n'])])
+                    g_adam = GraphedCallable(adam_step, warmup=1)
+                except Exception as e:           # e.g. a collective backend that does not tolerate the capture sequence:
+                    staged_graph_error = repr(e)[:300]       # same on every rank; run the staged step eagerly (as fast at
+                    use_graph = False                        # this size: 5.11 vs 5.09 ms at N = 1), still overlapped
+                    dp.wait_stages()
+                    torch.cuda.synchronize()
             elif world == 1 and not args.split_graph:
                 g_step = GraphedCallable(whole_step)                 # forward + ELBO + backward + Adam: one graph
             else:
@@ -666,6 +673,7 @@ def main():
             **({'gradient_exchange': {
                 'mode': 'staged backward: per-stage sum-all-reduce overlapped with the following stage',
                 'backward_stages': groups['stages'], 'exchange_groups': groups['n'],
+                **({'hipgraph_capture_failed_ran_eagerly': staged_graph_error} if staged_graph_error else {}),
                 'group_bytes': [4 * (opt.bucket.segments[g][1] - opt.bucket.segments[g][0]) if g in opt.bucket.segments else 0
                                 for g in range(groups['n'])]}} if staged else
                ({'gradient_exchange': {'mode': 'one sum-all-reduce of the flat bucket after the backward pass',
