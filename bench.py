@@ -35,6 +35,7 @@ import torch.distributed as dist  # noqa: E402
 M_INDUCING, S_SAMPLES, BATCH, N_DATA, SEED = 1024, 10, 4096, 100_000, 173
 MFMA_F32_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 MFMA_F64_PEAK_TFLOPS = 78.6           # v_mfma_f64_16x16x4_f64: half the f32 matrix rate
+MFMA_BF16_PEAK_TFLOPS = 2500.0        # v_mfma_f32_32x32x16_bf16, dense (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -369,9 +370,51 @@ def gibbs_map_step_ms(device, n):
     return round(e0.elapsed_time(e1) / 3, 3)
 
 
+def cpu_baseline_cfg5(rows=1024, M=2048, S=10, n_data=1_000_000, seconds_budget=30.0):
+    """The oracle's op sequence for BASELINE configs[4]'s model (3-layer = tied 3->3 hidden layer applied twice + last
+    3->1, M = 2048, S = 10) on the host cores: forward + backward + Adam in float32 with float64 Cholesky, Kzz / Cholesky
+    once per layer (the redundancy-free restatement; gpytorch-mirror mode would recompute them per sample).  A BOUNDED
+    sample: minibatch of `rows` rows instead of 4096 (a full step is minutes of CPU work).  Returns (seconds per sampled
+    step, steps timed)."""
+    from oracle import svgp
+    g = torch.Generator().manual_seed(SEED)
+    D = 3
+    sp = torch.nn.functional.softplus
+    hZ = torch.randn(3, M, D, generator=g).requires_grad_()
+    lZ = torch.randn(M, 3, generator=g).requires_grad_()
+    h_rl, h_ro, l_rl, l_ro, rn, lc = [torch.zeros(sh).requires_grad_() for sh in [(3, 1, D), (3,), (1, 3), (), (1,), (1,)]]
+    hm = (1e-3 * torch.randn(3, M, generator=g)).requires_grad_()
+    lm = (1e-3 * torch.randn(M, generator=g)).requires_grad_()
+    hL = torch.eye(M).repeat(3, 1, 1).requires_grad_()
+    lL = torch.eye(M).clone().requires_grad_()
+    hw, hb = torch.randn(D, 1, generator=g).requires_grad_(), torch.randn(1, generator=g).requires_grad_()
+    params = [hZ, lZ, h_rl, h_ro, l_rl, l_ro, rn, lc, hm, lm, hL, lL, hw, hb]
+    state, times = {}, []
+    t_all = time.perf_counter()
+    while True:
+        xb, yb = torch.randn(rows, D, generator=g), torch.randn(rows, generator=g)
+        eps = [torch.randn(S, rows, 3, generator=g) for _ in range(2)]
+        t0 = time.perf_counter()
+        hidden = dict(Z=hZ, lengthscale=sp(h_rl), outputscale=sp(h_ro), m=hm, Lq=hL, mean=('linear', hw, hb))
+        last = dict(Z=lZ, lengthscale=sp(l_rl), outputscale=sp(l_ro), m=lm, Lq=lL, mean=('constant', lc))
+        loss = -svgp.dsvi_elbo(xb, yb, hidden, last, 2, eps, S, sp(rn) + 1e-4, n_data, mirror=False)
+        grads = torch.autograd.grad(loss, params)
+        with torch.no_grad():
+            for p_, q in zip(params, svgp.adam_step([p_.detach() for p_ in params], list(grads), state)):
+                p_.copy_(q)
+        times.append(time.perf_counter() - t0)
+        if len(times) >= 2 and (time.perf_counter() - t_all > seconds_budget or len(times) >= 3):
+            break
+        if len(times) == 1 and time.perf_counter() - t_all > seconds_budget:
+            break
+    use = times[1:] if len(times) > 1 else times
+    return sum(use) / len(use), len(times)
+
+
 def main_cfg5(args):
     """BASELINE configs[4] on one GPU as a bench.py line (single process; the 8-GPU form of this config shares the
-    data-parallel path of the headline config)."""
+    data-parallel path of the headline config): `roofline` for the f32 GEMM family (+ the float64-accumulating and bf16
+    projection families), `cpu_baseline` from the oracle on a bounded sample."""
     if int(os.environ.get('WORLD_SIZE', '1')) != 1:
         raise SystemExit('--config cfg5 is a single-GPU run')
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
@@ -379,13 +422,41 @@ def main_cfg5(args):
     torch.cuda.set_device(0)
     pa = probe.parser().parse_args(['--steps', str(args.steps), '--warmup', str(args.warmup), '--forward', args.forward])
     r = probe.run(pa)
-    print(json.dumps({'metric': 'dsvi_elbo_steps_per_sec', 'value': r['steps_per_sec'], 'unit': 'steps/s', 'n_gpus': 1,
-                      'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': r['ms_per_step'], 'higher_is_better': True,
-                      'scaling': 'strong', 'vs_baseline': None,
-                      'dtype': 'f32' if args.forward == 'f32' else 'f32 (bf16 forward projections: ' + args.forward + ')',
-                      'data': 'synthetic', 'config': {'workload': r['workload'], 'M': 2048, 'S': 10, 'global_batch': 4096,
-                                                      'N': 1000000, 'parallelism': 'dp1', 'forward': args.forward},
-                      'detail': r}), flush=True)
+    ach = r['f32_gemm_TFLOPs']
+    line = {'metric': 'dsvi_elbo_steps_per_sec', 'value': r['steps_per_sec'], 'unit': 'steps/s', 'n_gpus': 1,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': r['ms_per_step'], 'higher_is_better': True,
+            'scaling': 'strong', 'vs_baseline': None,
+            'dtype': 'f32' if args.forward == 'f32' else 'f32 (bf16 forward projections: ' + args.forward + ')',
+            'data': 'synthetic', 'config': {'workload': r['workload'], 'M': 2048, 'S': 10, 'global_batch': 4096,
+                                            'N': 1000000, 'parallelism': 'dp1', 'forward': args.forward},
+            'roofline': {'bound': 'mfma', 'kernel': 'gemm_kernel<float,...> (all f32 GEMM launches of a step)',
+                         'achieved': ach, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
+                         'gemm_ms_per_step': r['f32_gemm_ms_per_step'], 'gemm_launches_per_step': r['f32_gemm_launches']},
+            'f64acc_projection': ({'ms_per_step': r['f64acc_gemm_ms_per_step'], 'launches_per_step': r['f64acc_gemm_launches'],
+                                   'achieved': r['f64acc_gemm_TFLOPs'], 'peak': MFMA_F64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                   'frac': round(r['f64acc_gemm_TFLOPs'] / MFMA_F64_PEAK_TFLOPS, 4)}
+                                  if r['f64acc_gemm_launches'] else None),
+            'bf16_projection': ({'ms_per_step': r['bf16_gemm_ms_per_step'], 'launches_per_step': r['bf16_gemm_launches'],
+                                 'achieved': r['bf16_gemm_TFLOPs'], 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                 'frac': round(r['bf16_gemm_TFLOPs'] / MFMA_BF16_PEAK_TFLOPS, 4)}
+                                if r['bf16_gemm_launches'] else None),
+            'detail': r}
+    if not args.no_cpu_baseline:
+        torch.set_num_threads(host_cores())
+        rows = 1024
+        sec, nsteps = cpu_baseline_cfg5(rows=rows)
+        # per-step CPU time is dominated by the O(M^2 n) projections (n proportional to the minibatch) plus the O(M^3)
+        # Cholesky chain; reported as steps/s of the SAMPLED minibatch and, scaled by rows / 4096, as a full-minibatch figure
+        line['cpu_baseline'] = {'value': round(1.0 / sec * rows / BATCH, 5), 'unit': 'steps/s', 'cores': torch.get_num_threads(),
+                                'kind': 'port',
+                                'sample': f'{nsteps} DSVI steps (first discarded when more than one) of the configs[4] model '
+                                          f'(M=2048, S=10, 3 layers) on a {rows}-row minibatch, oracle with Kzz + Cholesky once '
+                                          f'per layer; value = measured {1.0 / sec:.4f} steps/s x {rows}/{BATCH} (linear in the '
+                                          'minibatch: an upper bound on the CPU rate, the M^3 part does not shrink)',
+                                'sampled_steps_per_sec': round(1.0 / sec, 5), 'sampled_rows': rows}
+        line['speedup_vs_cpu'] = round(line['value'] / line['cpu_baseline']['value'], 1)
+    print(json.dumps(line), flush=True)
 
 
 def main():
@@ -514,6 +585,7 @@ def main():
         return loss.detach()
 
     def adam_step():
+        dp.check_drained()                   # every gradient exchange that was started has been waited on
         opt.step(gather=False)
 
     held = {}
@@ -565,15 +637,36 @@ def main():
             p0 = opt.bucket.flat_p.detach().clone()      # graph warm-up / capture runs real steps: undo them below
             if staged:
                 from nsgp.graph import GraphedSequence
+                capture_ok = 1
                 try:
+                    if os.environ.get('NSGP_BENCH_FAIL_CAPTURE', '') in ('all', str(rank)):      # test hook (tests/test_gpu_dist.py)
+                        raise RuntimeError(f'NSGP_BENCH_FAIL_CAPTURE: simulated capture failure on rank {rank}')
                     g_seq = GraphedSequence([stage_group_fn(gi) for gi in range(groups['n'])],
                                             [exchange_fn(gi) for gi in range(groups['n'])])
                     g_adam = GraphedCallable(adam_step, warmup=1)
-                except Exception as e:           # e.g. a collective backend that does not tolerate the capture sequence:
-                    staged_graph_error = repr(e)[:300]       # same on every rank; run the staged step eagerly (as fast at
-                    use_graph = False                        # this size: 5.11 vs 5.09 ms at N = 1), still overlapped
-                    dp.wait_stages()
-                    torch.cuda.synchronize()
+                except Exception as e:           # e.g. a collective backend that does not tolerate the capture sequence
+                    capture_ok = 0
+                    staged_graph_error = repr(e)[:300]
+                # The choice between graph replay and eager launches is made COLLECTIVELY (MIN over the ranks): a failure on
+                # one rank only must not leave the ranks on different paths.  Either path issues the same collectives in
+                # the same order; the eager path is as fast at this size (5.11 vs 5.09 ms at N = 1) and still overlapped.
+                if world > 1 or rehearse:
+                    flag = torch.tensor([capture_ok], dtype=torch.int32, device=device)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    capture_all = int(flag.item())
+                else:
+                    capture_all = capture_ok
+                if not capture_all:
+                    use_graph = False
+                    if staged_graph_error is None:
+                        staged_graph_error = 'capture failed on another rank'
+                    try:                         # a collective error surfaces here: never run on after it
+                        dp.wait_stages()
+                        torch.cuda.synchronize()
+                    except Exception as e2:
+                        print(f'bench.py: rank {rank}: device/collective error after the failed staged capture: {e2!r}',
+                              file=sys.stderr, flush=True)
+                        sys.exit(3)
             elif world == 1 and not args.split_graph:
                 g_step = GraphedCallable(whole_step)                 # forward + ELBO + backward + Adam: one graph
             else:
@@ -592,6 +685,7 @@ def main():
             torch._foreach_copy_([x_in, y_in], [xs[k % n_batches], ys[k % n_batches]])
             if staged and use_graph:
                 loss = g_seq()[0]
+                dp.check_drained()               # (adam_step's own check only runs at capture time)
                 g_adam()
             elif staged:
                 for gi in range(groups['n']):

@@ -1310,8 +1310,11 @@ int potrf_inv_impl(T* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int3
 template <typename T>
 int potrf_trtri_impl(T* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, int32_t* info, T* X, int64_t ldx, int64_t sX,
                      void* ws, size_t wsb, void* stream, float* X32 = nullptr, int* wrote32 = nullptr) {
+    // argument order of the C entry points: A 1, n 2, lda 3, sA 4, batch 5, info 6, X 7, ldx 8, sX 9 (as potrf_impl / trtri_impl)
     if (n < 0) return -2; if (batch < 0) return -5;
     if (n == 0 || batch == 0) return 0;
+    if (!A) return -1; if (lda < n) return -3; if (batch > 65535) return -5; if (!info) return -6;
+    if (!X) return -7; if (ldx < n) return -8;
     const size_t w1 = (size_t)batch * cdiv64(n, NB) * NB * NB * sizeof(T);
     const size_t w2 = n > NB ? (size_t)batch * n * n * sizeof(T) : 0;
     if (!ws || wsb < w1 + w2) return -11;

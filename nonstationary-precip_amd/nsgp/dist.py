@@ -69,6 +69,7 @@ class DataParallel:
         """force=True: issue the collectives even in a one-rank group (rehearsal of the N>1 call sequence on one GPU)."""
         self.bucket, self.group = bucket, group
         self._pending = []
+        self.stages_issued, self.stages_waited = 0, 0        # all-reduces started / joined (check_drained)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.active = self.world > 1 or (force and dist.is_initialized())
@@ -88,11 +89,22 @@ class DataParallel:
         if self.active and seg is not None and seg[1] > seg[0]:
             self._pending.append(dist.all_reduce(self.bucket.flat_g[seg[0]:seg[1]], op=dist.ReduceOp.SUM,
                                                  group=self.group, async_op=True))
+            self.stages_issued += 1
 
     def wait_stages(self):
-        for work in self._pending:
+        """Join every all-reduce `allreduce_stage` started (an exception of a collective propagates to the caller)."""
+        pending, self._pending = self._pending, []
+        for work in pending:
             work.wait()                       # device tensors: the current stream waits, the host does not block
-        self._pending = []
+            self.stages_waited += 1
+
+    def check_drained(self):
+        """Raise unless every exchange that was started has been waited on: the optimiser step must not read a bucket
+        range whose all-reduce is still in flight (call right before the Adam step)."""
+        if self._pending or self.stages_issued != self.stages_waited:
+            raise RuntimeError(f'DataParallel: {len(self._pending)} gradient all-reduce(s) still pending '
+                               f'({self.stages_issued} issued, {self.stages_waited} waited): call wait_stages() before '
+                               'the optimiser step')
 
     def allreduce_grads(self, async_op=False, gather=True):
         if gather:

@@ -82,6 +82,28 @@ def _ws(nbytes, device):
 # it first; across passes p.grad decides, so any way of clearing gradients is safe.
 # --------------------------------------------------------------------------------------------
 _grad_sinks = {}
+_grad_sinks_on = True
+
+
+class grad_sinks:
+    """Context manager / switch: `with ops.grad_sinks(False): ...` makes every backward pass inside hand its gradients
+    over in fresh buffers, as plain torch does.  Needed when gradients are taken with `torch.autograd.grad` (or kept across
+    `zero_grad()`): a sink's gradient IS a view of the optimiser's flat gradient bucket, so the next backward pass would
+    overwrite a tensor the caller still holds.  (Inside an ordinary `loss.backward()` the view becomes `p.grad` and the
+    aliasing is the point: the bucket is filled without a copy.)"""
+
+    def __init__(self, enabled):
+        self.enabled, self.prev = bool(enabled), None
+
+    def __enter__(self):
+        global _grad_sinks_on
+        self.prev, _grad_sinks_on = _grad_sinks_on, self.enabled
+        return self
+
+    def __exit__(self, *exc):
+        global _grad_sinks_on
+        _grad_sinks_on = self.prev
+        return False
 
 
 class _GradSink:
@@ -107,7 +129,7 @@ def unregister_grad_sinks(flat_g):
 def grad_sink(t):
     """(view shaped like t, accumulate) for a tensor that IS a registered parameter (same storage, same number of
     elements, contiguous) inside a backward pass, else None."""
-    s = _grad_sinks.get(t.data_ptr())
+    s = _grad_sinks.get(t.data_ptr()) if _grad_sinks_on else None
     if s is None:
         return None
     task = torch._C._current_graph_task_id()
@@ -684,22 +706,29 @@ def svgp_project_bf16(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None,
     C = torch.empty((batch, M, n), dtype=ref.dtype, device=ref.device)
     flops = 1.0 * M * M * n * batch
     if kernel_inputs is None:
-        # product 1 at full precision; its partials use the float32 plan's tile rows (>= T)
+        # product 1 at full precision.  Its partials are laid out with ITS kernel's tile rows: the float32 plan's (Tf), or
+        # the float64-accumulating kernel's (T64: 128-row tiles, 64-row ones when the 128-row grid is under one round --
+        # e.g. M = 1024, n = 4032, b = 1 gives Tf = 8 but T64 = 16).  One buffer with the largest count; rows a kernel does
+        # not fill stay zero, exactly as in svgp_project.
         Tf = int(lib.nsgp_svgp_colstats_tiles(M, n, batch, 4))
-        if Tf < T:
-            raise BackendError('svgp_project_bf16: tile-row mismatch')
+        T64 = int(lib.nsgp_svgp_f64acc_tiles_for(M, n, batch)) if W64f is not None else Tf
+        T1 = T64 if W64f is not None else Tf                       # tile rows product 1 writes
+        Tp = max(T1, T)
         A = torch.empty_like(Kzx)
-        part = torch.zeros((3, batch, max(Tf, 1), n), dtype=ref.dtype, device=ref.device) if Tf > T else \
-            torch.empty((3, batch, max(Tf, 1), n), dtype=ref.dtype, device=ref.device)
+        part = (torch.zeros if (T1 != Tp or T != Tp) else torch.empty)((3, batch, max(Tp, 1), n), dtype=ref.dtype,
+                                                                       device=ref.device)
         W = _c(W)
         if W64f is not None:
             _timed(lambda: _lib.call('nsgp_svgp_tri_gemm_colstats_f64acc', _p(_c(W64f)), _p(Kzx), _p(m), batch, M, n, _p(A),
-                                     _p(part[0]), _p(part[1]), Tf, st), flops, 'f64acc')
-        else:
+                                     _p(part[0]), _p(part[1]), Tp, st), flops, 'f64acc')
+        elif Tp == Tf:
             _timed(lambda: _lib.call('nsgp_svgp_tri_gemm_colstats_f32', _p(W), 0, _p(Kzx), _p(m), batch, M, n, _p(A),
                                      _p(part[0]), _p(part[1]), st), flops, ref.dtype)
+        else:
+            _timed(lambda: _lib.call('nsgp_svgp_tri_gemm_colstats_rows_f32', _p(W), 0, _p(Kzx), _p(m), batch, M, n, _p(A),
+                                     _p(part[0]), _p(part[1]), Tp, st), flops, ref.dtype)
         _lib.call('nsgp_transpose_cast_bf16', _p(A), _p(AT), batch, M, n, st)
-        if Tf != T:
+        if Tp != T:
             # the bf16 kernel lays its partials out with its own tile-row count: give it a compact buffer, then widen
             p2 = torch.empty((batch, T, n), dtype=ref.dtype, device=ref.device)
             _timed(lambda: _lib.call('nsgp_svgp_tri_gemm_colstats_bf16', _p(Ub), 2, _p(AT), None, batch, M, n, _p(C), None,
@@ -708,7 +737,7 @@ def svgp_project_bf16(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None,
         else:
             _timed(lambda: _lib.call('nsgp_svgp_tri_gemm_colstats_bf16', _p(Ub), 2, _p(AT), None, batch, M, n, _p(C), None,
                                      None, _p(part[2]), st), flops, 'bf16')
-        T = Tf
+        T = Tp
     else:
         Z, x, ls, os_ = kernel_inputs
         Z, ls, os_ = _c(Z), _c(ls), _c(os_.reshape(-1))

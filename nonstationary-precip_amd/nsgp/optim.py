@@ -17,7 +17,14 @@ class FlatBucket:
     `grads_as_views=True` (default): autograd accumulates straight into the bucket (`p.grad += g`, one small
     launch per parameter).  `grads_as_views=False`: `zero_grad()` drops the .grad tensors so autograd hands over
     its own buffers (no launch, no memset), and `gather_grads()` packs them into the bucket with one
-    multi-tensor copy -- fewer launches per step; FusedAdam and DataParallel call it themselves."""
+    multi-tensor copy -- fewer launches per step; FusedAdam and DataParallel call it themselves.
+
+    Aliasing with `grads_as_views=False` on the GPU: parameters of >= 65,536 elements are registered as gradient sinks
+    (`ops.register_grad_sink`), i.e. their backward kernels write the gradient straight into this bucket and autograd
+    receives a VIEW of `flat_g`.  After `loss.backward()` that view is `p.grad` (intended).  A gradient obtained with
+    `torch.autograd.grad(...)`, or a `p.grad` kept across `zero_grad()`, aliases the bucket too and is overwritten by the
+    next backward pass -- take such gradients inside `with nsgp.ops.grad_sinks(False):` (fresh buffers, as plain torch), or
+    clone them."""
 
     def __init__(self, params, grads_as_views=True, stage_of=None):
         seen, plist = set(), []

@@ -61,3 +61,31 @@ def test_product_never_imports_the_oracle():
             if f.endswith('.py'):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, re.M), os.path.join(dp, f)
+
+
+def test_potrf_trtri_rejects_bad_arguments_with_error_codes_not_faults():
+    """nsgp_potrf_trtri_* validate their pointers and leading dimensions before any launch, like nsgp_potrf /
+    nsgp_trtri (a negative return = index of the bad argument).  The checks run on the host: safe without a GPU."""
+    import nsgp
+    lib = nsgp.load_library()
+    buf = (ctypes.c_double * 16)()
+    info = (ctypes.c_int32 * 1)()
+    ws = (ctypes.c_char * 65536)()
+    P = lambda o: ctypes.cast(o, ctypes.c_void_p)
+    ok = dict(A=P(buf), n=2, lda=2, sA=4, batch=1, info=P(info), X=P(buf), ldx=2, sX=4)
+
+    def call(name, **kw):
+        a = dict(ok, **kw)
+        extra = (None, None) if name.endswith('w32') else ()
+        return getattr(lib, name)(a['A'], a['n'], a['lda'], a['sA'], a['batch'], a['info'], a['X'], a['ldx'], a['sX'], *extra,
+                                  P(ws), 65536, None)
+    for name in ('nsgp_potrf_trtri_f32', 'nsgp_potrf_trtri_f64', 'nsgp_potrf_trtri_f64_w32'):
+        assert call(name, A=None) == -1
+        assert call(name, n=-1) == -2
+        assert call(name, lda=1) == -3
+        assert call(name, batch=-1) == -5
+        assert call(name, batch=70000) == -5
+        assert call(name, info=None) == -6
+        assert call(name, X=None) == -7
+        assert call(name, ldx=1) == -8
+        assert call(name, n=0) == 0 and call(name, batch=0) == 0

@@ -111,3 +111,65 @@ def test_bf16_forward_at_the_cfg5_shape_states_its_error():
     assert all(bool(torch.isfinite(v).all()) for v in res['bf16'][2].values())
     # 'bf16_all' is a throughput figure: stated above, only required to be finite
     assert math.isfinite(res['bf16_all'][0])
+
+
+@pytest.mark.parametrize('b,M,n', [(2, 1024, 1950), (1, 1024, 4032), (1, 1024, 512)])
+def test_bf16_mode_with_f64_whitening_at_shapes_where_the_kernels_tile_rows_differ(b, M, n):
+    """forward_precision('bf16') with the float64-accumulating whitening product.  At these shapes the float32
+    plan uses 128-row tiles (8 tile rows) but the float64-accumulating kernel picks 64-row tiles (16 tile rows): the
+    partial buffers must hold the larger count (the call used to fail with -10 / BackendError)."""
+    _need_gpu()
+    from nsgp import ops
+    g = torch.Generator().manual_seed(M + n + b)
+    D = 3
+    Z = torch.randn(b, M, D, generator=g)
+    x = torch.randn(n, D, generator=g)
+    ls = torch.rand(b, D, generator=g) + 0.6
+    os_ = torch.rand(b, generator=g) + 0.5
+    W = torch.tril(torch.randn(b, M, M, generator=g)) / math.sqrt(M)
+    Lq = torch.tril(torch.randn(b, M, M, generator=g)) / math.sqrt(M) + torch.eye(M)
+    m = torch.randn(b, M, generator=g)
+    c = lambda t: t.cuda()
+    Kzx = ops.rbf_build(c(Z), c(x), c(ls), c(os_))
+    W64 = c(W).double()
+    A0, C0, mean0, var0 = ops.svgp_project(c(W), Kzx, c(Lq), c(m), c(os_), base_add=1e-4, W64f=W64)
+    A1, C1, mean1, var1 = ops.svgp_project_bf16(c(W), Kzx, c(Lq), c(m), c(os_), base_add=1e-4, W64f=W64)
+    assert torch.equal(A1, A0)                                       # product 1 is the same launch
+    assert torch.allclose(mean1, mean0, rtol=1e-6, atol=1e-6)
+    r = lambda t: t.to(torch.bfloat16).double()
+    C_ref = r(torch.tril(Lq)).transpose(-1, -2) @ r(A0.cpu())
+    assert float((C1.cpu().double() - C_ref).abs().max()) < 2e-4 * float(C_ref.abs().max()) + 1e-5
+    var_ref = os_.double().reshape(b, 1) + 1e-4 + (C1.cpu().double() ** 2).sum(1) - (A1.cpu().double() ** 2).sum(1)
+    assert torch.allclose(var1.cpu().double(), var_ref, rtol=1e-4, atol=1e-4 * float(var_ref.abs().max()))
+    # and without W64f (float32 product 1)
+    A2, C2, mean2, var2 = ops.svgp_project_bf16(c(W), Kzx, c(Lq), c(m), c(os_), base_add=1e-4)
+    A3, _, mean3, _ = ops.svgp_project(c(W), Kzx, c(Lq), c(m), c(os_), base_add=1e-4)
+    assert torch.equal(A2, A3) and torch.allclose(mean2, mean3, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize('forward', ['f32', 'bf16'])
+def test_configs4_full_shape_step_is_finite_decreases_the_loss_and_fits(forward):
+    """BASELINE configs[4] at its FULL per-GPU shape (3-layer, M = 2048, minibatch 4096, S = 10,
+    N = 1e6) through `bench.py --config cfg5`'s own runner (tools/dsvi_cfg5_probe.py: hipGraph-captured
+    fwd + ELBO + bwd + Adam).  The oracle cannot run this size in test time, so: size-independent properties -- every
+    loss finite, Adam decreases the objective over a few steps, peak HBM stays far below the 288 GB of the card."""
+    _need_gpu()
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'tools'))
+    import dsvi_cfg5_probe as probe
+    import models.dgps as m
+    old = m.num_output_dims
+    try:
+        r = probe.run(probe.parser().parse_args(['--steps', '8', '--warmup', '2', '--forward', forward]))
+    finally:
+        m.num_output_dims = old
+    print('configs[4] full shape, forward=%s: %.1f ms/step, loss %.4f -> %.4f, peak HBM %.2f GB, f32 GEMMs %.1f TFLOP/s'
+          % (forward, r['ms_per_step'], r['loss_first'], r['loss_last'], r['hbm_peak_allocated_GB'], r['f32_gemm_TFLOPs']))
+    assert math.isfinite(r['loss_first']) and math.isfinite(r['loss_last'])
+    assert r['loss_last'] < r['loss_first']
+    assert 1.0 < r['hbm_peak_allocated_GB'] < 40.0
+    assert r['f32_gemm_launches'] > 0 and (r['f64acc_gemm_launches'] > 0)
+    if forward == 'bf16':
+        assert r['bf16_gemm_launches'] > 0

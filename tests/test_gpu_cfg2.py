@@ -21,6 +21,10 @@ import torch
 
 pytestmark = pytest.mark.gpu
 F64 = torch.float64
+from conftest import measured  # noqa: E402
+
+# float32 model vs float64 oracle on the 900-row subset (36 inducing locations): ~3x the errors measured on MI355X
+OBJ_TOL, MEAN_TOL, VAR_TOL = 5e-3, 2e-3, 5e-3
 
 
 def _need_gpu():
@@ -140,7 +144,8 @@ def test_sparse_multivariate_gibbs_gp_matches_oracle_on_a_subset(data_dir):
     prior = psgibbs.MatrixNormalPrior(torch.zeros(36, 2), row, torch.eye(2))
     ref = ref + prior.log_prob(H.float()) / len(xd)
     # float32 kernel build + float32 M x M Cholesky of a kernel matrix with near-duplicate inducing points
-    assert abs(float(val) - float(ref)) < 5e-3 * abs(float(ref)), (float(val), float(ref))
+    print('[measured] configs[2] subset objective: rel err %.3g (bound %.1g)' % (abs(float(val) - float(ref)) / abs(float(ref)), OBJ_TOL))
+    assert abs(float(val) - float(ref)) < OBJ_TOL * abs(float(ref)), (float(val), float(ref))
     model.eval(); lik.eval()
     with torch.no_grad():
         pred = lik(model(xte.cuda()))
@@ -148,6 +153,80 @@ def test_sparse_multivariate_gibbs_gp_matches_oracle_on_a_subset(data_dir):
     rel = float((pred.loc.cpu().double() - m_ref).norm() / m_ref.norm())
     print('configs[2] subset: posterior mean 2-norm rel err %.3g, max-norm rel %.3g' % (
         rel, float((pred.loc.cpu().double() - m_ref).abs().max() / m_ref.abs().max())))
-    assert rel < 2e-3, rel
+    assert rel < MEAN_TOL, rel
     v, v_ref = torch.diagonal(pred.covariance_matrix).cpu().double(), torch.diagonal(c_ref)
-    assert torch.allclose(v, v_ref, rtol=5e-3, atol=5e-4), float((v - v_ref).abs().max())
+    assert measured('configs[2] subset predictive variance', v, v_ref, rtol=VAR_TOL, atol=0.1 * VAR_TOL)
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.float64])
+def test_sparse_multivariate_gibbs_gp_at_M512_with_the_jitter_pinned_on_both_sides(data_dir, monkeypatch, dt):
+    """configs[2] AT ITS OWN SIZE (M = 512 inducing locations) against the oracle.  Kzz of 512 locations
+    on 43 distinct grid cells is numerically singular, so the reference (psd_safe_cholesky) and this path both factor it
+    only after a precision-dependent jitter retry -- here the retry ladder is taken out of the comparison: BOTH sides
+    factor Kzz + J I with the same J = 1e-2 (the product's `chol_inv_safe` is patched to add exactly J, the oracle
+    receives Kzz + J I).  900 training rows, 150 test rows; float32 (what the config runs) and float64 models."""
+    _need_gpu()
+    import nsgp.gp as gpytorch
+    from nsgp import ops
+    from nsgp.gp.utils import cholesky as chol_mod
+    from oracle import psgibbs, sparse
+    J = 1e-2
+    x, y = _data(data_dir)
+    g = torch.Generator().manual_seed(7)
+    idx = torch.randperm(len(x), generator=g)
+    xj = x + 0.02 * torch.randn(x.shape, generator=g)
+    tr, te = idx[:900], idx[900:1050]
+    xtr, ytr, xte = xj[tr], y[tr], xj[te]
+    Z = _inducing(x)                                             # 512 k-means centres (+ 0.05 randn), as bench.py's B3 step
+    assert Z.shape == (512, 2)
+
+    def pinned(K, jitter=None, max_tries=3):
+        W, info = ops.chol_inv(K + J * torch.eye(K.shape[-1], dtype=K.dtype, device=K.device))
+        assert int(info.max().item()) == 0
+        return W
+    monkeypatch.setattr(chol_mod, 'chol_inv_safe', pinned)
+    model, lik = _model(xtr, ytr, Z)
+    if dt == torch.float64:
+        model, lik = model.double(), lik.double()
+        model.set_train_data(xtr.double().cuda(), ytr.double().cuda(), strict=False)
+    model.train(); lik.train()
+    mll = gpytorch.mlls.ExactMarginalLogLikelihood(lik, model)
+    val = mll(model(model.train_inputs[0]), model.train_targets)
+    val.backward()
+    k = model.covar_module.base_kernel.base_kernel
+    assert k.D.grad is not None and bool(torch.isfinite(k.D.grad).all())
+    sp = torch.nn.functional.softplus
+    H, Dm = k.H.detach().cpu().double(), k.D.detach().cpu().double()
+    os_ = float(sp(model.covar_module.base_kernel.raw_outputscale.detach().cpu().double()))
+    noise = float(sp(lik.noise_covar.raw_noise.detach().cpu().double()) + 1e-4)
+    ls = torch.full((1, 2), math.log(2.0), dtype=F64)
+    col = torch.eye(2, dtype=F64)
+    Zd, xd, xsd, yd = Z.double(), xtr.double(), xte.double(), ytr.double()
+
+    def K(a, b):
+        return os_ * psgibbs.mv_gibbs_forward(a, b, Zd, H, Dm, ls, col, row_os=math.log(2.0))
+    Kzz, Kxz, Ksz = K(Zd, Zd) + J * torch.eye(512, dtype=F64), K(xd, Zd), K(xsd, Zd)
+    kd_x, kd_s = os_ * torch.ones(len(xd), dtype=F64), os_ * torch.ones(len(xsd), dtype=F64)
+    ref = sparse.ipk_mll(Kzz, Kxz, kd_x, yd, noise)
+    from oracle import kernels as OKk
+    rdt = torch.float32 if dt == torch.float32 else F64
+    row = OKk.rbf_ard(Z.to(rdt), Z.to(rdt), torch.full((1, 2), math.log(2.0), dtype=rdt), math.log(2.0))
+    prior = psgibbs.MatrixNormalPrior(torch.zeros(512, 2, dtype=rdt), row, torch.eye(2, dtype=rdt))
+    ref = ref + prior.log_prob(H.to(rdt)) / len(xd)
+    obj_err = abs(float(val) - float(ref)) / abs(float(ref))
+    model.eval(); lik.eval()
+    with torch.no_grad():
+        pred = lik(model(xte.to(dt).cuda()))
+    m_ref, c_ref = sparse.ipk_predict(Kzz, Kxz, kd_x, Ksz, kd_s, yd, noise)
+    mean_err = float((pred.loc.cpu().double() - m_ref).abs().max() / m_ref.abs().max())
+    v, v_ref = torch.diagonal(pred.covariance_matrix).cpu().double(), torch.diagonal(c_ref)
+    var_err = float((v - v_ref).abs().max() / v_ref.abs().max())
+    kap = float(torch.linalg.cond(Kzz))
+    print('[measured] configs[2] at M=512, J=%.0e, %s: kappa(Kzz + J I) %.3g, objective rel err %.3g, posterior mean '
+          'max-norm rel err %.3g, variance max-norm rel err %.3g' % (J, str(dt)[6:], kap, obj_err, mean_err, var_err))
+    tol = M512_TOL[dt]
+    assert obj_err < tol[0] and mean_err < tol[1] and var_err < tol[2], (obj_err, mean_err, var_err)
+
+
+# (objective, posterior mean, predictive variance) bounds at M = 512 with J = 1e-2: ~3x the errors measured on MI355X
+M512_TOL = {torch.float32: (3e-2, 3e-2, 3e-2), torch.float64: (1e-8, 1e-8, 1e-8)}

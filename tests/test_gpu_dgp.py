@@ -9,6 +9,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 F64 = torch.float64
+# float32 DSVI step vs float64 oracle, per-parameter max-norm relative gradient error: ~3x the measured worst case
+DSVI_GRAD_TOL = 2e-2
 
 
 def _need_gpu():
@@ -125,8 +127,9 @@ def test_dsvi_elbo_and_gradients_match_oracle(num_layers, D, M, B, S, chol_bwd_f
         scale = float(want.abs().max()) + 1e-12
         err = float((got - want).abs().max()) / scale
         errs[name] = err
-        assert err < 2e-2, (name, err, chol_bwd_f64)         # per-parameter max-norm relative error
-    print('max grad rel err', chol_bwd_f64, max(errs.values()), max(errs, key=errs.get))
+        assert err < DSVI_GRAD_TOL, (name, err, chol_bwd_f64)         # per-parameter max-norm relative error
+    print('[measured] dsvi max grad rel err', (num_layers, D, M, B, S, chol_bwd_f64), '%.3g' % max(errs.values()), max(errs, key=errs.get),
+          '| elbo rel err %.3g' % (abs(float(elbo) - float(ref)) / abs(float(ref))))
 
 
 def test_negated_data_parallel_objective_is_minus_the_objective():

@@ -1,7 +1,7 @@
 """the north-star tolerance (posterior mean within 1e-4 relative error) asserted AT the headline
 shape -- BASELINE configs[3]: 2-layer DSVI DeepGP, M = 1024 inducing points, minibatch B = 4096, S = 10 likelihood
 samples, D = 3 -- after a few Adam steps from bench.py's own initialisation (so kappa(Kzz) is that of a model in
-training, not of the random init), float32 HIP path against the float64 CPU oracle (models/dgps.py:44-51,92-98
+training, not of the random init; 25 and 1000 steps), float32 HIP path against the float64 CPU oracle (models/dgps.py:44-51,92-98
 through gpytorch's whitened VariationalStrategy.forward).
 
 Error measure: max-norm relative error  max_i |got_i - ref_i| / max_i |ref_i|  per layer output (means AND
@@ -26,7 +26,10 @@ def _maxrel(got, ref):
     return float((got.double().cpu() - ref).abs().max() / ref.abs().max())
 
 
-def test_posterior_mean_within_1e4_at_the_headline_shape():
+@pytest.mark.parametrize('train_steps', [25, 1000])
+def test_posterior_mean_within_1e4_at_the_headline_shape(train_steps):
+    """train_steps = 25: a model early in training; 1000: kappa(Kzz) has moved with the inducing points / lengthscales
+    (the bound must hold along the training trajectory, not only near the initialisation)."""
     _need_gpu()
     if ROOT not in sys.path:
         sys.path.insert(0, ROOT)
@@ -44,7 +47,7 @@ def test_posterior_mean_within_1e4_at_the_headline_shape():
     model.train()
     g = torch.Generator().manual_seed(5)
     with settings.num_likelihood_samples(S):
-        for k in range(25):                                          # a few Adam steps (lr 0.01) on fresh minibatches
+        for k in range(train_steps):                                 # Adam steps (lr 0.01) on fresh minibatches
             rows = perm[(k % (N // B)) * B:(k % (N // B) + 1) * B]
             opt.zero_grad()
             loss = -mll(model(x_all[rows].to(dev)), y_all[rows].to(dev))
@@ -81,7 +84,7 @@ def test_posterior_mean_within_1e4_at_the_headline_shape():
     errs = dict(hidden_mean=_maxrel(h_mean.transpose(-1, -2), hm_ref), hidden_var=_maxrel(h_var.transpose(-1, -2), hv_ref),
                 out_mean=_maxrel(o_mean, om_ref), out_var=_maxrel(o_var, ov_ref),
                 elbo=abs(float(elbo) - float(elbo_ref)) / abs(float(elbo_ref)))
-    print('kappa(Kzz + 1e-4 I) [hidden 0, hidden 1, last]:', ['%.3g' % k_ for k_ in kap])
+    print(f'after {train_steps} Adam steps: kappa(Kzz + 1e-4 I) [hidden 0, hidden 1, last]:', ['%.3g' % k_ for k_ in kap])
     print('max-norm relative errors (f32 HIP vs f64 oracle):', {k: '%.3g' % v for k, v in errs.items()})
     assert errs['hidden_mean'] <= 1e-4, errs                        # the north-star bound, per layer
     assert errs['out_mean'] <= 1e-4, errs

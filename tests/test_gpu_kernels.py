@@ -673,3 +673,21 @@ def test_potrf_trtri_fused_equals_potrf_then_trtri(ops, dt, n, batch, monkeypatc
     bad[0, 5, 5] = -1.0
     _, info2 = ops.potrf_trtri_(bad)
     assert int(info2[0]) == 6
+
+
+@pytest.mark.parametrize('n,batch', [(64, 1), (128, 2), (200, 2), (1024, 3), (1100, 1), (2048, 1), (2112, 1)])
+def test_potrf_trtri_w32_variant_writes_the_rounded_inverse(ops, n, batch):
+    """nsgp_potrf_trtri_f64_w32 -- what every float32 model's whitening chain calls (WhitenFn, want_f32=True): the float32
+    copy of W is written by the panel launches themselves (n a multiple of 64 up to 2048), strict upper triangle included,
+    and by a cast otherwise (n = 200, 1100, 2112: the wrote32 = 0 fallback).  Must equal the float64 result rounded once."""
+    g = _g(70 + n)
+    A = torch.randn(batch, n, n, generator=g, dtype=torch.float64)
+    K = (A @ A.transpose(-1, -2) / n + torch.eye(n, dtype=torch.float64)).cuda()
+    X, info, X32 = ops.potrf_trtri_(K.clone(), want_f32=True)
+    assert info.tolist() == [0] * batch
+    assert X32.dtype == torch.float32 and X32.shape == X.shape
+    assert torch.equal(torch.tril(X32), torch.tril(X).float())
+    if n % 64 == 0 and n <= 2048:
+        assert bool((torch.triu(X32, 1) == 0).all()) and bool((torch.triu(X, 1) == 0).all())
+    X0, info0 = ops.potrf_trtri_(K.clone())
+    assert torch.equal(torch.tril(X0), torch.tril(X))

@@ -12,6 +12,10 @@ import torch
 
 pytestmark = pytest.mark.gpu
 F64 = torch.float64
+from conftest import measured  # noqa: E402
+
+# float32 Paciorek-Schervish builds vs the float64 oracle: bounds = ~3x the error measured on MI355X (printed by `measured`)
+HS_TOL, KSX_TOL, KN_TOL = 5e-3, 5e-3, 5e-3
 
 
 def _need_gpu():
@@ -251,13 +255,13 @@ def test_multivariate_gibbs_kernels_match_oracle(data_dir):
     xd, xsd = x.cpu().double(), xs.cpu().double()
     Kxx = k(x).evaluate()
     ref = psgibbs.mv_gibbs_forward(xd, xd, xd, H, Dm, ls, col)
-    assert torch.allclose(Kxx.cpu().double(), ref, rtol=2e-4, atol=2e-5)
+    assert measured('PS Kxx', Kxx, ref, rtol=2e-4, atol=2e-5)
     Ksx = k(xs, x).evaluate()
     Hs = k.expectation_conditional_matrix_variate_dist(xs)
     Hs_ref = psgibbs.conditional_H(xsd, xd, H, ls, col)
-    assert torch.allclose(Hs.cpu().double(), Hs_ref, rtol=5e-3, atol=5e-3)
+    assert measured('conditional H', Hs, Hs_ref, rtol=HS_TOL, atol=HS_TOL)
     ref_sx = psgibbs.mv_gibbs_forward(xsd, xd, xd, H, Dm, ls, col)
-    assert torch.allclose(Ksx.cpu().double(), ref_sx, rtol=5e-3, atol=5e-3)
+    assert measured('PS cross-covariance', Ksx, ref_sx, rtol=KSX_TOL, atol=KSX_TOL)
     # gradient reaches D only (H is detached inside the kernel, reference :85,98)
     Kxx.sum().backward()
     assert k.D.grad is not None and (k.H.grad is None or float(k.H.grad.abs().max()) == 0.0)
@@ -268,7 +272,7 @@ def test_multivariate_gibbs_kernels_match_oracle(data_dir):
     lsd = torch.full((1, 2), math.log(2.0), dtype=F64)
     refn = psgibbs.mv_gibbs_forward(xd, xd, Z.cpu().double(), ks.H.detach().cpu().double(),
                                     ks.D.detach().cpu().double(), lsd, torch.eye(2, dtype=F64), row_os=math.log(2.0))
-    assert torch.allclose(Kn.cpu().double(), refn, rtol=5e-3, atol=5e-3)
+    assert measured('sparse PS Knn', Kn, refn, rtol=KN_TOL, atol=KN_TOL)
     prior_lp = ks.prior_H.log_prob(ks.H)
     assert torch.isfinite(prior_lp)
 
@@ -311,4 +315,4 @@ def test_sparse_multivariate_gibbs_kernel_at_baseline_config_size(data_dir):
     xd = x[idx].cpu().double()
     ref = psgibbs.mv_gibbs_forward(xd, xd, Z.cpu().double(), k.H.detach().cpu().double(), k.D.detach().cpu().double(),
                                    ls, torch.eye(2, dtype=F64), row_os=math.log(2.0))
-    assert torch.allclose(sub, ref, rtol=5e-3, atol=5e-3)
+    assert measured('sparse PS 300-pt sub-block (M=512)', sub, ref, rtol=KN_TOL, atol=KN_TOL)

@@ -5,6 +5,11 @@ import torch
 
 pytestmark = pytest.mark.gpu
 F32, F64 = torch.float32, torch.float64
+from conftest import measured  # noqa: E402
+
+# float32 layer vs float64 oracle at small shapes (kappa(Kzz) ~ 1e4): ~3x the errors measured on MI355X
+F32_VALUE_TOL = dict(rtol=2e-3, atol=5e-4)
+F32_GRAD_TOL = 2e-2
 
 
 def _g(seed):
@@ -52,9 +57,9 @@ def test_svgp_layer_matches_oracle(dt, b, M, D, n, batched_x):
     assert info.cpu().tolist() == [0] * b
     # float32 layer: W (float64 Cholesky) is rounded to f32 and A = W Kzx runs on f32 MFMA, where the
     # reference rounds A after a float64 solve; with kappa(Kzz) ~ 1e4 here both agree to ~1e-4
-    tol = dict(rtol=1e-9, atol=1e-10) if dt == F64 else dict(rtol=2e-3, atol=5e-4)
-    assert torch.allclose(mean.detach().cpu().double(), mean_r, **tol)
-    assert torch.allclose(var.detach().cpu().double(), var_r, **tol)
+    tol = dict(rtol=1e-9, atol=1e-10) if dt == F64 else F32_VALUE_TOL
+    assert measured(f'svgp mean {dt} b{b} M{M}', mean, mean_r, **tol)
+    assert measured(f'svgp var {dt} b{b} M{M}', var, var_r, **tol)
     ((mean * gm.to(dt).cuda()).sum() + (var * gv.to(dt).cuda()).sum()).backward()
     gtol = dict(rtol=1e-7, atol=1e-8) if dt == F64 else dict(rtol=2e-2, atol=2e-2)
     names = ['x', 'Z', 'ls', 'os', 'm', 'Lq']
@@ -63,7 +68,8 @@ def test_svgp_layer_matches_oracle(dt, b, M, D, n, batched_x):
         ref = torch.tril(r) if name == 'Lq' else r
         scale = float(ref.abs().max()) + 1e-30
         err = float((got - ref).abs().max()) / scale
-        assert err < (1e-7 if dt == F64 else 2e-2), (name, err)
+        print(f'[measured] svgp grad {name} {dt} b{b} M{M}: max-norm rel err {err:.3g}')
+        assert err < (1e-7 if dt == F64 else F32_GRAD_TOL), (name, err)
 
 
 def test_svgp_layer_at_init_is_the_prior():
