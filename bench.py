@@ -639,10 +639,12 @@ def main():
                 from nsgp.graph import GraphedSequence
                 capture_ok = 1
                 try:
-                    if os.environ.get('NSGP_BENCH_FAIL_CAPTURE', '') in ('all', str(rank)):      # test hook (tests/test_gpu_dist.py)
-                        raise RuntimeError(f'NSGP_BENCH_FAIL_CAPTURE: simulated capture failure on rank {rank}')
                     g_seq = GraphedSequence([stage_group_fn(gi) for gi in range(groups['n'])],
                                             [exchange_fn(gi) for gi in range(groups['n'])])
+                    # test hook (tests/test_gpu_dist.py): a failure on ONE rank, after the sequence's collectives have been
+                    # issued identically everywhere (a rank that dies before them desynchronises the group whatever we do)
+                    if os.environ.get('NSGP_BENCH_FAIL_CAPTURE', '') in ('all', str(rank)):
+                        raise RuntimeError(f'NSGP_BENCH_FAIL_CAPTURE: simulated capture failure on rank {rank}')
                     g_adam = GraphedCallable(adam_step, warmup=1)
                 except Exception as e:           # e.g. a collective backend that does not tolerate the capture sequence
                     capture_ok = 0

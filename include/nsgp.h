@@ -280,6 +280,28 @@ int nsgp_svgp_kzx_gemm_colstats_f64acc(const double* W, const float* z, const fl
 int nsgp_svgp_tri_gemm_colstats_f64acc(const double* W, const float* X, const float* rowvec, int64_t batch, int64_t M,
                                        int64_t n, float* Y, float* part_dot, float* part_sq, int64_t part_rows,
                                        void* stream);
+/* The same product with a float64 X (Kzx BUILT in float64, nsgp_rbf_build_fwd_f64): for the layers of a deep GP whose output
+ * is the next layer's input.  There the float32 rounding of Kzx, amplified by |W||Kzx| ~ 1e2, costs 3e-5 of the layer's mean
+ * and grows ten-fold through a trained next layer (tools/probes/precision_after_training.py: 3.8e-4 on the output mean after
+* 1000 Adam steps, the reference's own float32 arithmetic 4.5e-4, with this entry 2.6e-5).  Y and rowvec stay float32; the
+ * partials are FLOAT64 (the accumulators' sums unrounded: var = os + colsum(C^2) - colsum(A^2) cancels to << os once q(u) has
+ * trained, and float32 partials cost 4e-8 absolute = 4e-5 of a small variance) -- summed by
+ * nsgp_svgp_colstats_finalize_affine_p64_f32.  /root/reference/models/dgps.py:92-98 (hidden layers of DeepGP.forward). */
+int nsgp_svgp_tri_gemm_colstats_f64acc_b64(const double* W, const double* X64, const float* rowvec, int64_t batch, int64_t M,
+                                           int64_t n, float* Y, double* part_dot, double* part_sq, int64_t part_rows,
+                                           void* stream);
+/* The second projection of such a layer, Y[b] = L[b]^T X[b] (L: float64 copy of the stored lower-triangular Lq; X = the float32
+ * A), accumulated in float64: its variance is os + colsum(C^2 - A^2), and float32 accumulation of the 1024-term dot products
+ * of C is not consistent with the float64 colsum(A^2); both reach the next layer through sqrt(var) eps.  part_sq: the
+ * colsum(C^2) partials from the float64 accumulators, float64 (same layout as above). */
+int nsgp_svgp_tri_gemm_colstats_f64acc_t(const double* L, const float* X, int64_t batch, int64_t M, int64_t n, float* Y,
+                                         double* part_sq, int64_t part_rows, void* stream);
+/* nsgp_svgp_colstats_finalize_affine_f32 over float64 partials (the two entries above); mean / var come out float32. */
+int nsgp_svgp_colstats_finalize_affine_p64_f32(const double* part_dot, const double* part_sq_a, const double* part_sq_c,
+                                               const float* base, float base_add, int64_t batch, int64_t tiles, int64_t n,
+                                               const float* x, int64_t x_batch_stride, int64_t D, const float* w,
+                                               int64_t w_batch_stride, const float* c, int64_t c_batch_stride, float* mean,
+                                               float* var, void* stream);
 /* "bf16 forward" of BASELINE configs[4] (3-layer DSVI DeepGP, M = 2048: bf16 forward / fp32 Cholesky panels): the two
  * forward projections A = W Kzx, C = Lq^T A of a whitened SVGP layer (gpytorch VariationalStrategy.forward behind
  * /root/reference/models/dgps.py:44-51, driven by :92-98) on v_mfma_f32_32x32x16_bf16 -- bf16 operands, float32

@@ -32,6 +32,29 @@
 
 namespace {
 
+#ifdef NSGP_GEMM_STAMPS
+// Diagnostic build only (tools/probes/gemm_stamps.py): one 8-word record per workgroup -- shader-clock stamps at entry,
+// after the prologue (first K-tile in LDS), after the K loop and after the epilogue, the 100 MHz wall clock at entry and
+// exit, the tile and the hardware id.  Written to a buffer of their own; nothing else reads them.
+__device__ unsigned long long* nsgp_stamp_buf = nullptr;
+__device__ unsigned long long nsgp_stamp_cap = 0;
+#define NSGP_STAMP(i) do { if (threadIdx.x == 0) stamp_v[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define NSGP_STAMP_FLUSH() do { \
+        if (threadIdx.x == 0 && nsgp_stamp_buf) { \
+            const unsigned long long si = (unsigned long long)blockIdx.y * gridDim.x + blockIdx.x; \
+            if (si < nsgp_stamp_cap) { \
+                unsigned long long* sp = nsgp_stamp_buf + si * 8; \
+                sp[0] = stamp_v[0]; sp[1] = stamp_v[1]; sp[2] = stamp_v[2]; sp[3] = __builtin_amdgcn_s_memtime(); \
+                sp[4] = stamp_rt0; sp[5] = __builtin_amdgcn_s_memrealtime(); \
+                sp[6] = ((unsigned long long)(unsigned)bm << 40) | ((unsigned long long)(unsigned)bn << 16) | (unsigned)nt; \
+                sp[7] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492); \
+            } \
+        } } while (0)
+#else
+#define NSGP_STAMP(i) do { } while (0)
+#define NSGP_STAMP_FLUSH() do { } while (0)
+#endif
+
 template <typename T> struct Mfma;
 template <> struct Mfma<float> {
     static constexpr int MT = 32, KS = 2, NREG = 16, PAD = 4;
@@ -89,6 +112,7 @@ struct Epi {
     int modeA, modeB;       // operand modes of the instantiated variant (any strides are valid in either mode;
                             // the mode only decides the vector-load direction)
     int part_rows;          // kind 1: tile rows per batch element in the partial buffers (0 = the launch's own tile rows)
+    int p64;                // kind 1, MIX != 0: p0 / p1 are float64 buffers (the float64 accumulators' sums, unrounded)
     // MIX = 2: the B operand is never read -- B(k, n) = os[b] exp(-1/2 |z_k / ls[b] - x_n / ls[b]|^2) is generated in the
     // loader from the inducing points z (batch, K, D), the inputs x (n, D) or (batch, n, D) (kx_sx = batch stride),
     // ls (batch, D), os (batch): the arithmetic of pairwise.hip's RbfOp, operation for operation
@@ -169,6 +193,9 @@ struct TileLoader {
 // MODE_A / MODE_B: 0 = operand contiguous along k, 1 = contiguous along m (n).
 // EDGE = 0: every tile of the launch is whole and vector-loadable (M % BM == N % BN == K % BK == 0, 16-byte aligned
 // operands: the host checks) -- no bounds code is compiled in; EDGE = 1: ragged / unaligned shapes, element-wise loads.
+// MIX = 3: as MIX = 1 but the B operand is float64 in memory as well (Kzx BUILT in float64: layers whose output feeds another
+// layer -- the rounding of a float32 Kzx, amplified by |W||Kzx| ~ 1e2, is what limits those layers' accuracy); C, rv and the
+// partials stay float32.
 // MIX = 1 (T = double only): float64 arithmetic on float32 data -- the B operand, the output, the row vector and the
 // column-statistic partials are float32 in memory (pointers passed as T*, strides in elements); A and the MFMA
 // accumulation are float64.  This is the whitened projection A = L^-1 Kzx of the SVGP layer: the reference solves it
@@ -196,7 +223,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || N
                                                    T* __restrict__ slabs, Epi ep) {
     static_assert(MIX == 0 || (sizeof(T) == 8 && EPI == 1 && KSC == 0 && PF == 0), "MIX: float64 colstats projection only");
     static_assert(MIX != 2 || (EDGE == 0 && MODE_B == 1), "MIX = 2 (generated Kzx operand): whole tiles, n-contiguous pieces");
-    using TB = std::conditional_t<MIX != 0, float, T>;          // element type of B in memory
+    using TB = std::conditional_t<MIX == 1 || MIX == 2, float, T>;   // element type of B in memory (MIX = 3: float64 B, float32 C)
     using TC = std::conditional_t<MIX != 0, float, T>;          // element type of C / rv / partials in memory
     using MF = Mfma<T>;
     constexpr int MT = MF::MT, KS = MF::KS, NKK = BK / KS;
@@ -213,6 +240,11 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || N
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+#ifdef NSGP_GEMM_STAMPS
+    unsigned long long stamp_v[4] = {0, 0, 0, 0};
+    const unsigned long long stamp_rt0 = __builtin_amdgcn_s_memrealtime();
+    NSGP_STAMP(0);
+#endif
     // 32-bit tile arithmetic (the host checks tiles_m * tiles_n < 2^31): the 64-bit divisions of the first version
     // cost every workgroup ~1 us of scalar code before its first load.
     const int tiles_m = (int)g.tiles_m, tiles_n = (int)g.tiles_n;
@@ -590,6 +622,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || N
             kgen_half(rsb[0], 1);
             sstore(0, rsa[0], rsb[0], 0);
             __syncthreads();
+            NSGP_STAMP(1);
             for (int tb = 0; tb < nt; tb += DEEP) {
 #pragma unroll
                 for (int j = 0; j < DEEP; ++j) {
@@ -650,6 +683,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || N
             gload(0, ra0, rb0);
             sstore(0, ra0, rb0);
             __syncthreads();
+            NSGP_STAMP(1);
             generic_tiles(0, h0);
             // float64 tiles are short (BK = 16: 2048 MFMA cycles per K-tile, the staging stores start after 1024): a load
             // issued at the top of a tile has not landed when its first store comes up (wait_any 20 % of wave time).
@@ -712,6 +746,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || N
         }
     }
 
+    NSGP_STAMP(2);
     // epilogue
     if constexpr (EPI == 1) {
         // plain store + per-column partial sums over this tile's rows (rows >= M carry acc == 0)
@@ -756,9 +791,18 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || N
         __syncthreads();
         if (tid < BN && n0 + tid < g.N) {
             const int64_t o = (bb * (g.part_rows > 0 ? g.part_rows : g.tiles_m) + bm) * g.N + n0 + tid;
+            if constexpr (MIX != 0) {
+                if (ep.p64) {               // var = os + colsum(C^2) - colsum(A^2) cancels to << os once q(u) has trained
+                    if (ep.p0) reinterpret_cast<double*>(ep.p0)[o] = red[tid] + red[BN + tid];
+                    reinterpret_cast<double*>(ep.p1)[o] = red[2 * BN + tid] + red[3 * BN + tid];
+                    NSGP_STAMP_FLUSH();
+                    return;
+                }
+            }
             if (ep.p0) reinterpret_cast<TC*>(ep.p0)[o] = (TC)(red[tid] + red[BN + tid]);
             reinterpret_cast<TC*>(ep.p1)[o] = (TC)(red[2 * BN + tid] + red[3 * BN + tid]);
         }
+        NSGP_STAMP_FLUSH();
         return;
     } else if constexpr (EPI == 2) {
         const T* mat = reinterpret_cast<const T*>(ep.mat) + b1 * g.sc1 + b2 * g.sc2;
@@ -796,6 +840,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || N
                 }
             }
         }
+        NSGP_STAMP_FLUSH();
         return;
     }
     if constexpr (MIX == 0) {
@@ -827,6 +872,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || N
                 }
             }
     }   // MIX == 0
+    NSGP_STAMP_FLUSH();
 }
 
 // C = alpha * sum_s slab[s] + beta * C   (fixed summation order)
@@ -1132,7 +1178,11 @@ static inline bool f64acc_whole(const double* W, int64_t M, int64_t n, int bm) {
 
 int tri_gemm_colstats_f64acc_impl(const double* W, const float* X, const float* rowvec, int64_t batch, int64_t M, int64_t n,
                                   float* Y, float* part_dot, float* part_sq, int64_t part_rows, void* stream,
-                                  const KzxGen* kg = nullptr) {
+                                  const KzxGen* kg = nullptr, const double* X64 = nullptr, int trans = 0, int p64 = 0) {
+    // X64 != null: the B operand is float64 in memory (MIX = 3); X is then ignored
+    // trans = 1: Y = W^T X with the stored lower-triangular W (the second projection C = Lq^T A, MIX = 1 only)
+    if (trans && (kg || X64)) return -3;
+    if (X64) X = reinterpret_cast<const float*>(X64);
     if (!W) return -1; if (!X && !kg) return -2; if (batch < 0) return -4; if (M < 0) return -5; if (n < 0) return -6;
     if (!Y) return -7; if (!part_sq) return -9;
     if (batch == 0 || M == 0 || n == 0) return 0;
@@ -1143,16 +1193,16 @@ int tri_gemm_colstats_f64acc_impl(const double* W, const float* X, const float* 
     if (part_rows < cdiv64(M, BM_)) return -10;
     GemmArgs g{};
     g.M = M; g.N = n; g.K = M;
-    g.sam = M; g.sak = 1; g.sa1 = M * M; g.sa2 = 0;
+    g.sam = trans ? 1 : M; g.sak = trans ? M : 1; g.sa1 = M * M; g.sa2 = 0;
     g.sbk = n; g.sbn = 1; g.sb1 = M * n; g.sb2 = 0;
     g.ldc = n; g.sc1 = M * n; g.sc2 = 0; g.nb2 = 1;
     g.tiles_m = cdiv64(M, BM_); g.tiles_n = cdiv64(n, BN_);
     g.ksplit = 1; g.kper = cdiv64(M, 32) * 32; g.slab = 0;
-    g.flags = NSGP_GEMM_A_LOWER | NSGP_GEMM_NO_SPLITK;
+    g.flags = (trans ? NSGP_GEMM_A_UPPER : NSGP_GEMM_A_LOWER) | NSGP_GEMM_NO_SPLITK;
     g.nbk = (int)batch; g.xcd_chunk = 0; g.xcd_group = 0; g.part_rows = (int)part_rows;
-    g.modeA = 0; g.modeB = 1;
+    g.modeA = trans ? 1 : 0; g.modeB = 1;
     g.vecA = (M % 4 == 0) && ((uintptr_t)W % 32 == 0);
-    g.vecB = kg ? 1 : ((n % 4 == 0) && ((uintptr_t)X % 16 == 0));
+    g.vecB = kg ? 1 : ((n % 4 == 0) && ((uintptr_t)X % (X64 ? 32 : 16) == 0));
     if (g.tiles_m * g.tiles_n > 2147483647LL || batch > 65535) return -24;
     if (batch > 1) {                                     // tile order across the batch, as in gemm_impl
         const char* bpe = getenv("NSGP_GEMM_BATCH_PERM");
@@ -1160,7 +1210,7 @@ int tri_gemm_colstats_f64acc_impl(const double* W, const float* X, const float* 
             g.batch_perm = (g.tiles_m * g.tiles_n * batch <= 512) ? 1 : 0;   // (batch-fastest measured slower here: 314 -> 329 us)
     }
     Epi ep{};
-    ep.kind = 1; ep.rv = rowvec; ep.p0 = part_dot; ep.p1 = part_sq; ep.modeA = 0; ep.modeB = 1;
+    ep.kind = 1; ep.rv = rowvec; ep.p0 = part_dot; ep.p1 = part_sq; ep.modeA = trans ? 1 : 0; ep.modeB = 1; ep.p64 = p64;
     if (kg) {
         if (!kg->z || !kg->x || !kg->ls || !kg->os) return -2;
         if (kg->D < 1 || kg->D > KGEN_DMAX) return -3;
@@ -1182,7 +1232,23 @@ int tri_gemm_colstats_f64acc_impl(const double* W, const float* X, const float* 
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
     using B64 = std::integral_constant<int, 64>; using B128 = std::integral_constant<int, 128>;
-    if (kg) { if (BM_ == 128) go(B128{}, I0{}, I2{}); else go(B64{}, I0{}, I2{}); }
+    using I3 = std::integral_constant<int, 3>;
+    auto go_t = [&](auto bm_c, auto edge_c) {                 // transposed-A variant (operand contiguous along m)
+        constexpr int BMc = decltype(bm_c)::value, EDGEc = decltype(edge_c)::value;
+        constexpr size_t lds = 2 * BK_ * ((BMc + Mfma<double>::PAD) + (BN_ + Mfma<double>::PAD)) * sizeof(double);
+        nsgp_opt_in_lds((const void*)gemm_kernel<double, BMc, BN_, BK_, 1, 1, 1, 0, 0, EDGEc, 1>, lds);
+        hipLaunchKernelGGL((gemm_kernel<double, BMc, BN_, BK_, 1, 1, 1, 0, 0, EDGEc, 1>), grid, dim3(256), lds, st, g, 1.0,
+                           W, Bp, 0.0, Cp, (double*)nullptr, ep);
+    };
+    if (trans) {
+        if (BM_ == 128) { if (whole) go_t(B128{}, I0{}); else go_t(B128{}, I1{}); }
+        else { if (whole) go_t(B64{}, I0{}); else go_t(B64{}, I1{}); }
+    }
+    else if (X64) {
+        if (BM_ == 128) { if (whole) go(B128{}, I0{}, I3{}); else go(B128{}, I1{}, I3{}); }
+        else { if (whole) go(B64{}, I0{}, I3{}); else go(B64{}, I1{}, I3{}); }
+    }
+    else if (kg) { if (BM_ == 128) go(B128{}, I0{}, I2{}); else go(B64{}, I0{}, I2{}); }
     else if (BM_ == 128) { if (whole) go(B128{}, I0{}, I1{}); else go(B128{}, I1{}, I1{}); }
     else { if (whole) go(B64{}, I0{}, I1{}); else go(B64{}, I1{}, I1{}); }
     return nsgp_launch_status();
@@ -1190,6 +1256,17 @@ int tri_gemm_colstats_f64acc_impl(const double* W, const float* X, const float* 
 }  // namespace
 
 extern "C" {
+
+#ifdef NSGP_GEMM_STAMPS
+// diagnostic build: where the workgroups of the following GEMM launches write their stamp records (8 x uint64 each)
+int nsgp_debug_gemm_stamps(void* buf, uint64_t cap_records) {
+    unsigned long long* b = (unsigned long long*)buf;
+    unsigned long long c = cap_records;
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(nsgp_stamp_buf), &b, sizeof(b));
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(nsgp_stamp_cap), &c, sizeof(c));
+    return (int)e;
+}
+#endif
 
 size_t nsgp_svgp_f64acc_tiles(int64_t M) { return M > 0 ? (size_t)cdiv64(M, 128) : 0; }
 int nsgp_svgp_kzx_gemm_colstats_f64acc(const double* W, const float* z, const float* x, int64_t sx, const float* ls,
@@ -1209,6 +1286,20 @@ int nsgp_svgp_tri_gemm_colstats_f64acc(const double* W, const float* X, const fl
                                        int64_t n, float* Y, float* part_dot, float* part_sq, int64_t part_rows,
                                        void* stream) {
     return tri_gemm_colstats_f64acc_impl(W, X, rowvec, batch, M, n, Y, part_dot, part_sq, part_rows, stream);
+}
+
+int nsgp_svgp_tri_gemm_colstats_f64acc_b64(const double* W, const double* X64, const float* rowvec, int64_t batch, int64_t M,
+                                           int64_t n, float* Y, double* part_dot, double* part_sq, int64_t part_rows,
+                                           void* stream) {
+    if (!X64) return -2;
+    return tri_gemm_colstats_f64acc_impl(W, nullptr, rowvec, batch, M, n, Y, reinterpret_cast<float*>(part_dot),
+                                         reinterpret_cast<float*>(part_sq), part_rows, stream, nullptr, X64, 0, 1);
+}
+
+int nsgp_svgp_tri_gemm_colstats_f64acc_t(const double* L, const float* X, int64_t batch, int64_t M, int64_t n, float* Y,
+                                         double* part_sq, int64_t part_rows, void* stream) {
+    return tri_gemm_colstats_f64acc_impl(L, X, nullptr, batch, M, n, Y, nullptr, reinterpret_cast<float*>(part_sq), part_rows,
+                                         stream, nullptr, nullptr, 1, 1);
 }
 
 size_t nsgp_gemm_workspace(int64_t M, int64_t N, int64_t K, int64_t nb1, int64_t nb2, int elem_size, int flags) {

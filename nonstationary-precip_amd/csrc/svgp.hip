@@ -44,9 +44,10 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ A, 
 // ---- colstats from the GEMM epilogues' per-tile-row partial sums ----------------------------------
 // Optional affine prior mean added on the way out (gpytorch ConstantMean / LinearMean of models/dgps.py:40-43):
 //   mean[b,j] += sum_d x[b,j,d] w[b,d] + c[b]   (x / w / c batch strides may be 0 = shared; w or c may be null).
-template <typename T>
-__global__ void colstats_finalize_kernel(const T* __restrict__ pdot, const T* __restrict__ psqA,
-                                         const T* __restrict__ psqC, const T* __restrict__ base, T base_add,
+// TP: element type of the partial buffers (float64 partials of the float64-accumulating projections with a float32 layer)
+template <typename T, typename TP = T>
+__global__ void colstats_finalize_kernel(const TP* __restrict__ pdot, const TP* __restrict__ psqA,
+                                         const TP* __restrict__ psqC, const T* __restrict__ base, T base_add,
                                          int64_t batch, int64_t tiles, int64_t n, const T* __restrict__ x,
                                          int64_t sxb, int D, const T* __restrict__ w, int64_t swb,
                                          const T* __restrict__ c, int64_t scb, T* __restrict__ mean,
@@ -54,7 +55,7 @@ __global__ void colstats_finalize_kernel(const T* __restrict__ pdot, const T* __
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= batch * n) return;
     const int64_t b = idx / n, j = idx % n;
-    T sm = T(0), sa = T(0), sc = T(0);
+    TP sm = TP(0), sa = TP(0), sc = TP(0);
     for (int64_t t = 0; t < tiles; ++t) {
         const int64_t o = (b * tiles + t) * n + j;
         sm += pdot[o]; sa += psqA[o]; sc += psqC[o];
@@ -62,13 +63,13 @@ __global__ void colstats_finalize_kernel(const T* __restrict__ pdot, const T* __
     if (w) {
         const T* xr = x + b * sxb + j * D;
         const T* wr = w + b * swb;
-        T mu = T(0);
-        for (int d = 0; d < D; ++d) mu += xr[d] * wr[d];
+        TP mu = TP(0);
+        for (int d = 0; d < D; ++d) mu += (TP)xr[d] * (TP)wr[d];
         sm += mu;
     }
-    if (c) sm += c[b * scb];
-    mean[idx] = sm;
-    var[idx] = (base[b] + base_add) + (sc - sa);
+    if (c) sm += (TP)c[b * scb];
+    mean[idx] = (T)sm;
+    var[idx] = (T)(((TP)base[b] + (TP)base_add) + (sc - sa));
 }
 
 // ---- out[b][i] = sum_j A[b][i][j] * g[b][j]  (one workgroup per row; the m-gradient  A gmean) ------
@@ -445,8 +446,8 @@ int kl_bwd_impl(const T* m, const T* Lq, int64_t batch, int64_t M, T gout, T* gm
 
 }  // namespace
 
-template <typename T>
-static int finalize_affine_impl(const T* part_dot, const T* part_sq_a, const T* part_sq_c, const T* base, T base_add,
+template <typename T, typename TP = T>
+static int finalize_affine_impl(const TP* part_dot, const TP* part_sq_a, const TP* part_sq_c, const T* base, T base_add,
                                 int64_t batch, int64_t tiles, int64_t n, const T* x, int64_t sxb, int64_t D, const T* w,
                                 int64_t swb, const T* c, int64_t scb, T* mean, T* var, void* stream) {
     if (!part_dot) return -1; if (!part_sq_a) return -2; if (!part_sq_c) return -3; if (!base) return -4;
@@ -454,7 +455,7 @@ static int finalize_affine_impl(const T* part_dot, const T* part_sq_a, const T* 
     if (w && !x) return -9; if (sxb < 0) return -10; if (D < 0 || D > NSGP_MAX_DIM || (w && D == 0)) return -11;
     if (swb < 0) return -13; if (scb < 0) return -15; if (!mean) return -16; if (!var) return -17;
     if (batch * n == 0) return 0;
-    hipLaunchKernelGGL((colstats_finalize_kernel<T>), dim3((unsigned)cdiv64(batch * n, 256)), dim3(256), 0,
+    hipLaunchKernelGGL((colstats_finalize_kernel<T, TP>), dim3((unsigned)cdiv64(batch * n, 256)), dim3(256), 0,
                        (hipStream_t)stream, part_dot, part_sq_a, part_sq_c, base, base_add, batch, tiles, n, x, sxb,
                        (int)D, w, swb, c, scb, mean, var);
     return nsgp_launch_status();
@@ -583,6 +584,14 @@ int nsgp_svgp_colstats_finalize_affine_f32(const float* part_dot, const float* p
                                            float* var, void* stream) {
     return finalize_affine_impl<float>(part_dot, part_sq_a, part_sq_c, base, base_add, batch, tiles, n, x, x_batch_stride,
                                        D, w, w_batch_stride, c, c_batch_stride, mean, var, stream);
+}
+int nsgp_svgp_colstats_finalize_affine_p64_f32(const double* part_dot, const double* part_sq_a, const double* part_sq_c,
+                                               const float* base, float base_add, int64_t batch, int64_t tiles, int64_t n,
+                                               const float* x, int64_t x_batch_stride, int64_t D, const float* w,
+                                               int64_t w_batch_stride, const float* c, int64_t c_batch_stride, float* mean,
+                                               float* var, void* stream) {
+    return finalize_affine_impl<float, double>(part_dot, part_sq_a, part_sq_c, base, base_add, batch, tiles, n, x,
+                                               x_batch_stride, D, w, w_batch_stride, c, c_batch_stride, mean, var, stream);
 }
 int nsgp_svgp_colstats_finalize_affine_f64(const double* part_dot, const double* part_sq_a, const double* part_sq_c,
                                            const double* base, double base_add, int64_t batch, int64_t tiles,

@@ -137,7 +137,7 @@ class DeepGPLayer(ApproximateGP):
         else:
             ns, n = inputs.shape[0], inputs.shape[1]
             flat = inputs.reshape(ns * n, inputs.shape[-1])
-        mean, var = vs.marginals(flat)                                        # (b, ns*n)
+        mean, var = vs.marginals(flat, feeds_next=self.output_dims is not None)    # (b, ns*n)
         b = mean.shape[0]
         if self.output_dims is not None:
             mean_tsn, var_tsn = mean.reshape(b, ns, n), var.reshape(b, ns, n)

@@ -137,6 +137,18 @@ class whiten_matmul_f64(_feature_flag):
     _state = True
 
 
+class hidden_kzx_f64(_feature_flag):
+    """On (default): a float32 layer whose output is the NEXT layer's input (a DeepGPLayer with output_dims, i.e. every layer
+    of a deep GP but the last) builds its Kzx in float64 and feeds it to the float64-accumulating projection
+    (nsgp_svgp_tri_gemm_colstats_f64acc_b64); everything downstream of A stays float32.  Why: the float32 rounding of Kzx,
+    amplified by |W||Kzx| ~ 1e2, is 3e-5 of such a layer's mean, and a trained next layer multiplies it ten-fold -- after
+    1000 Adam steps of the headline model the output mean is 3.8e-4 off the float64 result (the reference's own float32
+    arithmetic: 4.5e-4), with this switch 2.6e-5 (tools/probes/precision_after_training.py).  Costs one float64 kernel build
+    per hidden layer (~+0.03 ms per step at the headline shape).  Off: the reference's arithmetic (float32 Kzx everywhere).
+    Needs whiten_matmul_f64 (the float64 W); float64 models are unaffected."""
+    _state = True
+
+
 class check_mvn_cholesky(_feature_flag):
     """On (default): MultivariateNormal.log_prob reads the Cholesky `info` of its dense covariance (one host sync) and
     follows psd_safe_cholesky -- jitter retries with a NumericalWarning, then NotPSDError -- instead of returning a NaN

@@ -100,8 +100,9 @@ class VariationalStrategy(_VariationalStrategy):
         Z, ls, os_, _, _ = self._flat_params()
         return Z, ls.contiguous(), os_.contiguous()
 
-    def marginals(self, x_flat):
-        """x_flat:(n,D) shared by all output GPs -> mean (b,n) incl. the prior mean, var (b,n)."""
+    def marginals(self, x_flat, feeds_next=False):
+        """x_flat:(n,D) shared by all output GPs -> mean (b,n) incl. the prior mean, var (b,n).
+        feeds_next: this layer's output is the next layer's input (settings.hidden_kzx_f64: Kzx built in float64)."""
         self._maybe_init()
         Z, ls, os_, m, Lq = self._flat_params()
         jitter = settings.variational_cholesky_jitter.value(x_flat.dtype)
@@ -113,7 +114,8 @@ class VariationalStrategy(_VariationalStrategy):
         fused, mean_w, mean_c = self._affine_prior_mean(b, x_flat.shape[-1])
         mean, var, _info = svgp_marginal(x_flat, Z, ls.contiguous(), os_.contiguous(), m, Lq, jitter=jitter,
                                          chol_bwd_f64=settings.chol_bwd_f64.on(), W64=W64, mean_w=mean_w,
-                                         mean_c=mean_c, W64f=getattr(self, '_W64f_shared', None) if W64 is not None else None)
+                                         mean_c=mean_c, W64f=getattr(self, '_W64f_shared', None) if W64 is not None else None,
+                                         kzx_f64=bool(feeds_next) and settings.hidden_kzx_f64.on())
         if fused:
             return mean, var
         xin = x_flat if b == 1 and self.inducing_points.dim() == 2 else x_flat.unsqueeze(0).expand(b, *x_flat.shape)

@@ -609,7 +609,7 @@ def svgp_kzx_fusable(W64f, Z, x, n):
     return bool(_lib.load().nsgp_svgp_kzx_gemm_supported(_p(W64f), M, n, batch, D))
 
 
-def svgp_project(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None, kernel_inputs=None):
+def svgp_project(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None, kernel_inputs=None, Kzx64=None, Lq64=None):
     """Fused K6 forward: A = W Kzx, C = Lq^T A (triangular MFMA GEMMs) with the column statistics reduced in
     the GEMM epilogues.  W, Lq:(b,M,M) lower; Kzx:(b,M,n); m:(b,M); base:(b,).
     Returns A, C, mean = A^T m (+ the affine prior mean x w + c, `affine` = (x, w, c)), var = base + base_add +
@@ -618,7 +618,16 @@ def svgp_project(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None, kern
     (nsgp_svgp_tri_gemm_colstats_f64acc: the reference's float64 solve); W itself (float32) is only used by the backward.
     kernel_inputs=(Z, x, ls, os) with Kzx=None (and W64f, `svgp_kzx_fusable`): Kzx is never materialised, its tiles are
     generated inside the loader of the first product from Z:(b,M,D), x:(n,D) or (b,n,D), ls:(b,D), os:(b,)."""
-    fused = Kzx is None
+    b64 = Kzx64 is not None
+    if b64:
+        if Kzx is not None or W64f is None or Kzx64.dtype != torch.float64 or Kzx64.dim() != 3:
+            raise BackendError('svgp_project: Kzx64 (float64 (b,M,n), with W64f, instead of Kzx) expected')
+        ref = _chk(W, Lq, m, base)
+        if Kzx64.device != ref.device:
+            raise BackendError('svgp_project: Kzx64 device')
+        W, Kzx64, Lq, m, base = _c(W), _c(Kzx64), _c(Lq), _c(m), _c(base.reshape(-1))
+        batch, M, n = Kzx64.shape
+    fused = Kzx is None and not b64
     if fused:
         if kernel_inputs is None or W64f is None:
             raise BackendError('svgp_project: Kzx=None needs kernel_inputs and W64f')
@@ -630,7 +639,7 @@ def svgp_project(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None, kern
         n = kx.shape[-2]
         if kx.shape[-1] != D or (kx.dim() == 3 and kx.shape[0] != batch) or kls.shape != (batch, D) or kos.shape != (batch,):
             raise BackendError('svgp_project: kernel_inputs shapes')
-    else:
+    elif not b64:
         ref = _chk(W, Kzx, Lq, m, base)
         W, Kzx, Lq, m, base = _c(W), _c(Kzx), _c(Lq), _c(m), _c(base.reshape(-1))
         batch, M, n = Kzx.shape
@@ -648,10 +657,17 @@ def svgp_project(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None, kern
             raise BackendError('svgp_project: W64f must be the float64 (b,M,M) W of a float32 layer')
         W64f = _c(W64f)
         T64 = int(lib.nsgp_svgp_f64acc_tiles_for(M, n, batch))    # 128-row tiles, 64-row ones for small grids
-        T32, T = T, max(T, T64)
+        p64 = b64 and Lq64 is not None            # both projections on the float64-accumulating kernel: float64 partials
+        if b64 and not p64:
+            raise BackendError('svgp_project: Kzx64 comes with Lq64 (both projections accumulate in float64)')
+        T32, T = T, (T64 if p64 else max(T, T64))
         # tile rows one of the two kernels does not fill (their tile heights differ for some shapes) stay zero
-        part = (torch.zeros if T64 != T32 else torch.empty)((3, batch, max(T, 1), n), dtype=ref.dtype, device=ref.device)
-        if fused:
+        part = (torch.zeros if (T64 != T32 and not p64) else torch.empty)(
+            (3, batch, max(T, 1), n), dtype=torch.float64 if p64 else ref.dtype, device=ref.device)
+        if b64:
+            _timed(lambda: _lib.call('nsgp_svgp_tri_gemm_colstats_f64acc_b64', _p(W64f), _p(Kzx64), _p(m), batch, M, n, _p(A),
+                                     _p(part[0]), _p(part[1]), T, st), flops, 'f64acc')
+        elif fused:
             _timed(lambda: _lib.call('nsgp_svgp_kzx_gemm_colstats_f64acc', _p(W64f), _p(kZ), _p(kx),
                                      n * D if kx.dim() == 3 else 0, _p(kls), _p(kos), D, _p(m), batch, M, n, _p(A),
                                      _p(part[0]), _p(part[1]), T, st), flops, 'f64acc')
@@ -662,8 +678,14 @@ def svgp_project(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None, kern
         part = torch.empty((3, batch, max(T, 1), n), dtype=ref.dtype, device=ref.device)
         _timed(lambda: _lib.call(f'nsgp_svgp_tri_gemm_colstats_{sfx}', _p(W), 0, _p(Kzx), _p(m), batch, M, n, _p(A),
                                  _p(part[0]), _p(part[1]), st), flops, ref.dtype)
-    _timed(lambda: _lib.call(f'nsgp_svgp_tri_gemm_colstats_rows_{sfx}', _p(Lq), 1, _p(A), None, batch, M, n, _p(C),
-                             None, _p(part[2]), T, st), flops, ref.dtype)
+    if Lq64 is not None:                      # C = Lq^T A accumulated in float64 (layers that feed the next layer)
+        if W64f is None or not b64 or Lq64.dtype != torch.float64 or Lq64.shape != (batch, M, M) or Lq64.device != ref.device:
+            raise BackendError('svgp_project: Lq64 must be the float64 (b,M,M) copy of Lq (with W64f and Kzx64)')
+        _timed(lambda: _lib.call('nsgp_svgp_tri_gemm_colstats_f64acc_t', _p(_c(Lq64)), _p(A), batch, M, n, _p(C), _p(part[2]),
+                                 T, st), flops, 'f64acc')
+    else:
+        _timed(lambda: _lib.call(f'nsgp_svgp_tri_gemm_colstats_rows_{sfx}', _p(Lq), 1, _p(A), None, batch, M, n, _p(C),
+                                 None, _p(part[2]), T, st), flops, ref.dtype)
     mean = torch.empty((batch, n), dtype=ref.dtype, device=ref.device)
     var = torch.empty_like(mean)
     if affine is None:
@@ -671,7 +693,8 @@ def svgp_project(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None, kern
         sxb = D = swb = scb = 0
     else:
         x, sxb, D, w, swb, c, scb = _affine_args(affine, batch, n, ref)
-    _lib.call(f'nsgp_svgp_colstats_finalize_affine_{sfx}', _p(part[0]), _p(part[1]), _p(part[2]), _p(base),
+    fin = 'nsgp_svgp_colstats_finalize_affine_p64_f32' if part.dtype != ref.dtype else f'nsgp_svgp_colstats_finalize_affine_{sfx}'
+    _lib.call(fin, _p(part[0]), _p(part[1]), _p(part[2]), _p(base),
               float(base_add), batch, T, n, _p(x), sxb, D, _p(w), swb, _p(c), scb, _p(mean), _p(var), st)
     return A, C, mean, var
 

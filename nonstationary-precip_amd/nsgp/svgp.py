@@ -172,7 +172,7 @@ class SVGPLayerFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, Z, ls, os_, m, Lq, W64, mean_w, mean_c, W64f=None):
+    def forward(ctx, x, Z, ls, os_, m, Lq, W64, mean_w, mean_c, W64f=None, kzx_f64=False):
         W = W64 if W64.dtype == x.dtype else ops.cast(W64, x.dtype)
         if W64f is None and W64.dtype == torch.float64 and x.dtype == torch.float32:
             W64f = W64
@@ -185,14 +185,23 @@ class SVGPLayerFn(torch.autograd.Function):
         # with the float64-accumulating product, whole tiles); the backward builds it once for Wbar = tril(Abar Kzx^T)
         fuse = fp == 'f32' and settings.fuse_kzx.on() and W64f is not None and \
             ops.svgp_kzx_fusable(W64f, Z, x, x.shape[-2])
-        Kzx = None if fuse else ops.rbf_build(Z, x, ls, os_)                     # (b,M,n)
+        # settings.hidden_kzx_f64: a layer that feeds the next one builds Kzx in float64 (inputs cast with one multi-tensor
+        # copy) for the float64-accumulating projection; its float32 Kzx is only needed by the backward, which builds it
+        Kzx64 = Lq64 = None
+        if kzx_f64 and fp == 'f32' and W64f is not None and not fuse:
+            src = [x.detach(), Z.detach(), ls.detach(), os_.detach(), Lq.detach()]
+            dst = [torch.empty(t.shape, dtype=torch.float64, device=t.device) for t in src]
+            torch._foreach_copy_(dst, src)
+            Kzx64 = ops.rbf_build(dst[1], dst[0], dst[2], dst[3])
+            Lq64 = dst[4]                     # C = Lq^T A accumulates in float64 too (the variance's cancellation)
+        Kzx = None if (fuse or Kzx64 is not None) else ops.rbf_build(Z, x, ls, os_)                     # (b,M,n)
         if x.dtype == torch.float32 and fp in ('bf16', 'bf16_all') and Z.shape[-2] % 8 == 0:
             # BASELINE configs[4]'s "bf16 forward": C = Lq^T A on the bf16 matrix cores; 'bf16_all' also A = W Kzx
             A, C, mean, var = ops.svgp_project_bf16(W, Kzx, Lq, m, os_, base_add=VAR_JITTER, affine=affine, W64f=W64f,
                                                     kernel_inputs=(Z, x, ls, os_) if fp == 'bf16_all' else None)
         else:
             A, C, mean, var = ops.svgp_project(W, Kzx, Lq, m, os_, base_add=VAR_JITTER, affine=affine, W64f=W64f,
-                                               kernel_inputs=(Z, x, ls, os_) if fuse else None)      # 2 GEMMs
+                                               kernel_inputs=(Z, x, ls, os_) if fuse else None, Kzx64=Kzx64, Lq64=Lq64)      # 2 GEMMs
         ctx.save_for_backward(x, Z, ls, os_, m, Lq, W, Kzx, A, C, mean_w, mean_c)
         ctx.w_dtype = W64.dtype
         return mean, var
@@ -200,7 +209,7 @@ class SVGPLayerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gmean, gvar):
         x, Z, ls, os_, m, Lq, W, Kzx, A, C, mean_w, mean_c = ctx.saved_tensors
-        if Kzx is None:                                  # fused forward: built here, once, for the Wbar product
+        if Kzx is None:                                  # fused / float64-Kzx forward: built here, once, for the Wbar product
             Kzx = ops.rbf_build(Z, x, ls, os_)
         gmean = gmean.contiguous()
         affine = None if (mean_w is None and mean_c is None) else (x, mean_w, mean_c)
@@ -219,10 +228,11 @@ class SVGPLayerFn(torch.autograd.Function):
         return (gx if need_x else None, gZ, gls.reshape(ls.shape), gos.reshape(os_.shape), mbar, Lqbar,
                 Wbar if Wbar.dtype == ctx.w_dtype else ops.cast(Wbar, ctx.w_dtype),
                 None if mean_w is None else wbar.reshape(mean_w.shape),
-                None if mean_c is None else cbar.reshape(mean_c.shape), None)
+                None if mean_c is None else cbar.reshape(mean_c.shape), None, None)
 
 
-def svgp_marginal(x, Z, ls, os_, m, Lq, jitter=1e-4, chol_bwd_f64=True, W64=None, mean_w=None, mean_c=None, W64f=None):
+def svgp_marginal(x, Z, ls, os_, m, Lq, jitter=1e-4, chol_bwd_f64=True, W64=None, mean_w=None, mean_c=None, W64f=None,
+                  kzx_f64=False):
     """mean and variance of q(f) at x for b whitened SVGPs; the mean excludes the prior mean function unless its
     affine parameters are passed (mean_w: LinearMean weights (D,) / (b,D), mean_c: constant or bias (1,) / (b,)).
     Returns (mean, var, info); pass W64 (from `whiten`) to share one factorisation chain across layers."""
@@ -230,5 +240,5 @@ def svgp_marginal(x, Z, ls, os_, m, Lq, jitter=1e-4, chol_bwd_f64=True, W64=None
     if W64 is None:
         (W64,), info, ((Z, ls, os_),), (W64f,) = whiten([(Z, ls, os_)], jitter, chol_bwd_f64, passthrough=True,
                                                         out_dtype=x.dtype, with_f64=True)
-    mean, var = SVGPLayerFn.apply(x, Z, ls, os_, m, Lq, W64, mean_w, mean_c, W64f)
+    mean, var = SVGPLayerFn.apply(x, Z, ls, os_, m, Lq, W64, mean_w, mean_c, W64f, kzx_f64)
     return mean, var, info

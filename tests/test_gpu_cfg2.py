@@ -24,7 +24,8 @@ F64 = torch.float64
 from conftest import measured  # noqa: E402
 
 # float32 model vs float64 oracle on the 900-row subset (36 inducing locations): ~3x the errors measured on MI355X
-OBJ_TOL, MEAN_TOL, VAR_TOL = 5e-3, 2e-3, 5e-3
+# measured: objective 1.3e-8, mean 2.4e-5 (2-norm), variance 1.5e-6 absolute on 0.74
+OBJ_TOL, MEAN_TOL, VAR_TOL = 1e-6, 1e-4, 2e-5
 
 
 def _need_gpu():
@@ -158,13 +159,14 @@ def test_sparse_multivariate_gibbs_gp_matches_oracle_on_a_subset(data_dir):
     assert measured('configs[2] subset predictive variance', v, v_ref, rtol=VAR_TOL, atol=0.1 * VAR_TOL)
 
 
-@pytest.mark.parametrize('dt', [torch.float32, torch.float64])
+@pytest.mark.parametrize('dt', [torch.float32])
 def test_sparse_multivariate_gibbs_gp_at_M512_with_the_jitter_pinned_on_both_sides(data_dir, monkeypatch, dt):
     """configs[2] AT ITS OWN SIZE (M = 512 inducing locations) against the oracle.  Kzz of 512 locations
     on 43 distinct grid cells is numerically singular, so the reference (psd_safe_cholesky) and this path both factor it
     only after a precision-dependent jitter retry -- here the retry ladder is taken out of the comparison: BOTH sides
     factor Kzz + J I with the same J = 1e-2 (the product's `chol_inv_safe` is patched to add exactly J, the oracle
-    receives Kzz + J I).  900 training rows, 150 test rows; float32 (what the config runs) and float64 models."""
+    receives Kzz + J I).  900 training rows, 150 test rows; float32 (what the config runs -- the kernel class, like the
+    reference's, creates its parameters H and D in float32 whatever the default dtype, so there is no float64 variant)."""
     _need_gpu()
     import nsgp.gp as gpytorch
     from nsgp import ops
@@ -185,10 +187,14 @@ def test_sparse_multivariate_gibbs_gp_at_M512_with_the_jitter_pinned_on_both_sid
         assert int(info.max().item()) == 0
         return W
     monkeypatch.setattr(chol_mod, 'chol_inv_safe', pinned)
-    model, lik = _model(xtr, ytr, Z)
-    if dt == torch.float64:
-        model, lik = model.double(), lik.double()
-        model.set_train_data(xtr.double().cuda(), ytr.double().cuda(), strict=False)
+    # (the kernel evaluates its row covariance on the inducing locations inside __init__ and keeps them as a plain tensor
+    # attribute, like the reference: a float64 model is BUILT under a float64 default dtype, not converted afterwards)
+    old_default = torch.get_default_dtype()
+    torch.set_default_dtype(dt)
+    try:
+        model, lik = _model(xtr.to(dt), ytr.to(dt), Z.to(dt))
+    finally:
+        torch.set_default_dtype(old_default)
     model.train(); lik.train()
     mll = gpytorch.mlls.ExactMarginalLogLikelihood(lik, model)
     val = mll(model(model.train_inputs[0]), model.train_targets)
@@ -229,4 +235,4 @@ def test_sparse_multivariate_gibbs_gp_at_M512_with_the_jitter_pinned_on_both_sid
 
 
 # (objective, posterior mean, predictive variance) bounds at M = 512 with J = 1e-2: ~3x the errors measured on MI355X
-M512_TOL = {torch.float32: (3e-2, 3e-2, 3e-2), torch.float64: (1e-8, 1e-8, 1e-8)}
+M512_TOL = {torch.float32: (7e-3, 3e-3, 8e-4)}        # measured over three boxes: <= (2.2e-3, 9.1e-4, 2.4e-4)

@@ -10,7 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 F64 = torch.float64
 # float32 DSVI step vs float64 oracle, per-parameter max-norm relative gradient error: ~3x the measured worst case
-DSVI_GRAD_TOL = 2e-2
+DSVI_GRAD_TOL = 6e-4          # measured worst case 1.8e-4 (fp32 Cholesky adjoint), 9e-5 with the float64 adjoint
 
 
 def _need_gpu():
@@ -117,8 +117,8 @@ def test_dsvi_elbo_and_gradients_match_oracle(num_layers, D, M, B, S, chol_bwd_f
     hidden, last, noise, leaves = _oracle_layers(model)
     ref = svgp.dsvi_elbo(x.double(), y.double(), hidden, last, num_layers, [e.double() for e in eps], S, noise, N)
     ref.backward()
-    # float32 pipeline vs float64 oracle: ELBO to 2e-4 relative
-    assert abs(float(elbo) - float(ref)) < 2e-4 * abs(float(ref)) + 1e-5
+    # float32 pipeline vs float64 oracle: ELBO (measured <= 1.6e-7 relative)
+    assert abs(float(elbo) - float(ref)) < 2e-6 * abs(float(ref)) + 1e-7
     errs = {}
     for name, p in _model_params(model).items():
         got, want = p.grad.detach().cpu().double(), leaves[name].grad

@@ -15,7 +15,8 @@ F64 = torch.float64
 from conftest import measured  # noqa: E402
 
 # float32 Paciorek-Schervish builds vs the float64 oracle: bounds = ~3x the error measured on MI355X (printed by `measured`)
-HS_TOL, KSX_TOL, KN_TOL = 5e-3, 5e-3, 5e-3
+# measured: conditional H max|diff| 1.5e-3 (|ref| 5.8), cross-covariance 9.4e-4, sparse Knn 8.3e-5 / 1.2e-4 (M = 512)
+HS_TOL, KSX_TOL, KN_TOL = 1e-3, 1.5e-3, 4e-4
 
 
 def _need_gpu():
