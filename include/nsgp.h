@@ -411,6 +411,32 @@ int nsgp_gauss_ell_bwd_f64(const double* y, const double* mu, const double* v, c
  *   gauss_ell_total: out[0] = scale * sum_s sum_i E_q log N(y_i | f_si, noise)   (fold 1/S, 1/B, sign into scale);
  *       backward with gout a 1-element DEVICE scalar (no host round trip, no per-sample gradient vector)
  *   kl_whitened_total: out[0] = scale * sum_b KL(N(m_b, Lq_b Lq_b^T) || N(0, I));  backward: scale * gout[0] * dKL */
+/* The whole DSVI objective as one scalar -- DeepApproximateMLL(VariationalELBO(...)) of /root/reference/models/dgps.py's model,
+ * driven at /root/reference/experiments/deepgp_spatial_bench.py:61,84-88 -- in TWO launches forward and TWO backward:
+ *   out[0] = ell_scale * sum_s sum_i E_q log N(y_i | f_si, noise)
+ *          + kl_scale  * sum_g sum_b KL(N(m_gb, Lq_gb Lq_gb^T) || N(0, I))           (fold 1/(B S), beta/num_data, signs into the scales)
+ * mu, v:(S,n); `ngroups` <= 8 variational groups (one per layer: tied layers counted once) given as HOST arrays of device
+ * pointers m[g]:(batch[g], M), Lq[g]:(batch[g], M, M) (lower triangle used) and host batch[g]; all groups share M.
+ * Backward: gout[0] (device) is the upstream gradient; writes gmu, gv:(S,n), gnoise[0] (optional), gm[g], gLq[g] (shapes of
+ * m / Lq; the strict upper triangle of gLq is zero).  ws: nsgp_dsvi_objective_workspace bytes.  The per-term entry points
+ * below stay for single-layer / non-whitened models. */
+size_t nsgp_dsvi_objective_workspace(int64_t S, int64_t n, int64_t M, int64_t total_batch, int elem_size);
+int nsgp_dsvi_objective_fwd_f32(const float* y, const float* mu, const float* v, const float* noise, int64_t S, int64_t n,
+                                float ell_scale, int ngroups, const void* const* m, const void* const* Lq,
+                                const int64_t* batch, int64_t M, float kl_scale, float* out, void* ws, size_t wsb,
+                                void* stream);
+int nsgp_dsvi_objective_fwd_f64(const double* y, const double* mu, const double* v, const double* noise, int64_t S, int64_t n,
+                                double ell_scale, int ngroups, const void* const* m, const void* const* Lq,
+                                const int64_t* batch, int64_t M, double kl_scale, double* out, void* ws, size_t wsb,
+                                void* stream);
+int nsgp_dsvi_objective_bwd_f32(const float* y, const float* mu, const float* v, const float* noise, int64_t S, int64_t n,
+                                float ell_scale, int ngroups, const void* const* m, const void* const* Lq,
+                                const int64_t* batch, int64_t M, float kl_scale, const float* gout, float* gmu, float* gv,
+                                float* gnoise, void* const* gm, void* const* gLq, void* ws, size_t wsb, void* stream);
+int nsgp_dsvi_objective_bwd_f64(const double* y, const double* mu, const double* v, const double* noise, int64_t S, int64_t n,
+                                double ell_scale, int ngroups, const void* const* m, const void* const* Lq,
+                                const int64_t* batch, int64_t M, double kl_scale, const double* gout, double* gmu, double* gv,
+                                double* gnoise, void* const* gm, void* const* gLq, void* ws, size_t wsb, void* stream);
 int nsgp_gauss_ell_total_fwd_f32(const float* y, const float* mu, const float* v, const float* noise, int64_t S,
                                  int64_t n, float scale, float* out, void* ws, size_t ws_bytes, void* stream);
 int nsgp_gauss_ell_total_fwd_f64(const double* y, const double* mu, const double* v, const double* noise, int64_t S,

@@ -33,7 +33,7 @@
 namespace {
 
 #ifdef NSGP_GEMM_STAMPS
-// Diagnostic build only (tools/probes/gemm_stamps.py): one 8-word record per workgroup -- shader-clock stamps at entry,
+// Diagnostic build only (tools/probes/gemm_stamps.py): one 16-word record per workgroup -- shader-clock stamps at entry,
 // after the prologue (first K-tile in LDS), after the K loop and after the epilogue, the 100 MHz wall clock at entry and
 // exit, the tile and the hardware id.  Written to a buffer of their own; nothing else reads them.
 __device__ unsigned long long* nsgp_stamp_buf = nullptr;
@@ -43,16 +43,24 @@ __device__ unsigned long long nsgp_stamp_cap = 0;
         if (threadIdx.x == 0 && nsgp_stamp_buf) { \
             const unsigned long long si = (unsigned long long)blockIdx.y * gridDim.x + blockIdx.x; \
             if (si < nsgp_stamp_cap) { \
-                unsigned long long* sp = nsgp_stamp_buf + si * 8; \
+                unsigned long long* sp = nsgp_stamp_buf + si * 16; \
                 sp[0] = stamp_v[0]; sp[1] = stamp_v[1]; sp[2] = stamp_v[2]; sp[3] = __builtin_amdgcn_s_memtime(); \
                 sp[4] = stamp_rt0; sp[5] = __builtin_amdgcn_s_memrealtime(); \
                 sp[6] = ((unsigned long long)(unsigned)bm << 40) | ((unsigned long long)(unsigned)bn << 16) | (unsigned)nt; \
+                sp[8] = stamp_bar; \
                 sp[7] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492); \
             } \
         } } while (0)
+// barrier of the K loop with the cycles this wave waited at it added up (the s_memtime round trips cost ~2 % of a K-tile)
+#define NSGP_LOOP_BARRIER() do { \
+        const unsigned long long b0_ = __builtin_amdgcn_s_memtime(); \
+        __syncthreads(); \
+        stamp_bar += __builtin_amdgcn_s_memtime() - b0_; \
+    } while (0)
 #else
 #define NSGP_STAMP(i) do { } while (0)
 #define NSGP_STAMP_FLUSH() do { } while (0)
+#define NSGP_LOOP_BARRIER() __syncthreads()
 #endif
 
 template <typename T> struct Mfma;
@@ -65,6 +73,8 @@ template <> struct Mfma<float> {
     static __device__ __forceinline__ int krow(int lane) { return lane >> 5; }      // k index of the operand lane
     static __device__ __forceinline__ int mcol(int lane) { return lane & 31; }      // m / n index of the operand lane
     static __device__ __forceinline__ int crow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+    static __device__ __forceinline__ int crow_lane(int lane) { return 4 * (lane >> 5); }          // crow = crow_lane + crow_reg
+    static __device__ __forceinline__ constexpr int crow_reg(int r) { return (r & 3) + 8 * (r >> 2); }
     static __device__ __forceinline__ int ccol(int lane) { return lane & 31; }
 };
 template <> struct Mfma<double> {
@@ -76,6 +86,8 @@ template <> struct Mfma<double> {
     static __device__ __forceinline__ int krow(int lane) { return lane >> 4; }
     static __device__ __forceinline__ int mcol(int lane) { return lane & 15; }
     static __device__ __forceinline__ int crow(int r, int lane) { return (lane >> 4) + 4 * r; }
+    static __device__ __forceinline__ int crow_lane(int lane) { return lane >> 4; }
+    static __device__ __forceinline__ constexpr int crow_reg(int r) { return 4 * r; }
     static __device__ __forceinline__ int ccol(int lane) { return lane & 15; }
 };
 
@@ -216,6 +228,9 @@ struct TileLoader {
 #ifndef NSGP_F64_DEPTH
 #define NSGP_F64_DEPTH 2
 #endif
+#ifndef NSGP_GEMM_ROLL
+#define NSGP_GEMM_ROLL 1
+#endif
 template <typename T, int BM, int BN, int BK, int MODE_A, int MODE_B, int EPI = 0, int KSC = 0, int PF = 0, int EDGE = 1,
           int MIX = 0>
 __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || NSGP_MIX_WG3)) ? 3 : ((sizeof(T) == 8 && BM == 128 && BK == 32) ? 1 : 2)) void gemm_kernel(GemmArgs g, T alpha, const T* __restrict__ A,
@@ -242,6 +257,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || N
     const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
 #ifdef NSGP_GEMM_STAMPS
     unsigned long long stamp_v[4] = {0, 0, 0, 0};
+    unsigned long long stamp_bar = 0;                    // cycles wave 0 spent at the K loop's barriers
     const unsigned long long stamp_rt0 = __builtin_amdgcn_s_memrealtime();
     NSGP_STAMP(0);
 #endif
@@ -631,7 +647,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || N
                     if (t + DEEP < nt) issue(t + DEEP, j);
                     ktile(j & 1, t + 1 < nt, std::integral_constant<int, FULLMASK>{}, std::true_type{}, rsa[(j + 1) % DEEP],
                           rsb[(j + 1) % DEEP], (j + 1) % DEEP);
-                    __syncthreads();
+                    NSGP_LOOP_BARRIER();
                 }
             }
         }
@@ -643,11 +659,23 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || N
             // no branch at all -- bare vector loads, every MFMA, every staging store.  With the choice between loader paths /
             // MFMA masks inside ONE loop hipcc carried the accumulators and the staging registers through phi copies (two
             // register sets, 64 v_mov per K-tile, spills inside the loop).
+            // ROLL (float32 kernels, NSGP_GEMM_ROLL): the hot loop also takes the diagonal blocks of triangular operands -- they
+            // are masked as they are stored, and a wave whose rows / columns lie entirely in an operand's zero part for a
+            // stretch of K-tiles runs a copy of the loop without the MFMAs for that stretch (below) -- so "regular" only means
+            // "whole".  (A deeper prefetch was tried on top: the load of the K-tile after next issued INTO the registers whose
+            // contents the ds_write in front of it had just sent to LDS -- in-place inline-asm loads with hand-counted vmcnt,
+            // because the compiler hoists such a load into fresh registers and copies them back behind a wait.  One wave alone
+            // on its SIMD went from 5400 to 5280 cycles per 4096-cycle K-tile: the stall is not in the loads; and hipcc may
+            // copy an asm-loaded register before the hand-placed wait -- it did in the 64 x 64 kernel's last tile, wrong
+            // results.  Dropped.)
+            constexpr bool ROLL = NSGP_GEMM_ROLL && sizeof(T) == 4 && KSC == 0;
             auto regular = [&](int t) __attribute__((always_inline)) {
                 const int64_t k0 = kbeg + (int64_t)t * BK;
                 if (k0 + BK > kend) return false;
-                if ((aL || aU) && (k0 < m0 + BM) && (k0 + BK > m0)) return false;
-                if ((bL || bU) && (k0 < n0 + BN) && (k0 + BK > n0)) return false;
+                if constexpr (!ROLL) {
+                    if ((aL || aU) && (k0 < m0 + BM) && (k0 + BK > m0)) return false;
+                    if ((bL || bU) && (k0 < n0 + BN) && (k0 + BK > n0)) return false;
+                }
                 return true;
             };
             int r0 = 0, r1 = 0;
@@ -677,7 +705,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || N
                     // skipped MFMA tiles only ever multiply the zeros the loader wrote).
                     if (mk == 0) ktile(buf, more, std::integral_constant<int, 0>{}, std::true_type{}, ra0, rb0);
                     else ktile(buf, more, std::integral_constant<int, FULLMASK>{}, std::true_type{}, ra0, rb0);
-                    __syncthreads();
+                    NSGP_LOOP_BARRIER();
                 }
             };
             gload(0, ra0, rb0);
@@ -691,7 +719,94 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || N
             // t - 1 and issues the loads of tile t + 2.
             constexpr bool DEPTH2 = sizeof(T) == 8 && KSC == 0;
             int hend = h0;                                                   // first tile the hot loop did NOT run
-            if (!DEPTH2 && h1 > h0) {
+            if constexpr (ROLL) {
+                // tiles t of [h0, h1): tile t + 1 is whole.  Tile t loads tile t + 1 at its top and stores it piece by piece in
+                // its second half, diagonal blocks of triangular operands masked on the way (a uniform branch around the
+                // select code; the MFMA part of the body is the same for every tile).
+                if (h1 > h0) {
+                    // K-tiles [lo, hi) in which THIS WAVE has work: its 64 rows against a triangular A, its columns against a
+                    // triangular B, nothing at all for a wave above the diagonal of a lower-only output.  Outside that range
+                    // the wave stages operands and keeps the barriers but issues no MFMA (a second copy of the loop): its SIMD
+                    // goes to the co-resident workgroup.  (The one-tile-ahead generic loop that used to take the diagonal K-tiles
+                    // ran them 40 % slower than the hot loop: 4 of a tile's 4..32 K-tiles, 8 us of a 92 us workgroup --
+                    // tools/probes/gemm_stamps.py.)
+                    int lo = h0, hi = h1;
+                    {
+                        const int64_t R0 = m0 + wm0, C0 = n0 + wn0;
+                        if (aL) { const int64_t e = (R0 + WM - kbeg + BK - 1) / BK; if (e < hi) hi = (int)(e > 0 ? e : 0); }
+                        if (aU) { const int64_t b = R0 > kbeg ? (R0 - kbeg) / BK : 0; if (b > lo) lo = (int)b; }
+                        if (bU) { const int64_t e = (C0 + WN - kbeg + BK - 1) / BK; if (e < hi) hi = (int)(e > 0 ? e : 0); }
+                        if (bL) { const int64_t b = C0 > kbeg ? (C0 - kbeg) / BK : 0; if (b > lo) lo = (int)b; }
+                        if (cmask_tile == 0) { lo = h0; hi = h0; }
+                        if (lo > h1) lo = h1;
+                        if (hi < lo) hi = lo;
+                        lo = __builtin_amdgcn_readfirstlane(lo);
+                        hi = __builtin_amdgcn_readfirstlane(hi);
+                    }
+                    const T* pa = la.cur + (int64_t)(h0 + 1) * BK * la.kstep;
+                    const TB* pb = lb.cur + (int64_t)(h0 + 1) * BK * lb.kstep;
+                    const int64_t da = (int64_t)BK * la.kstep, db = (int64_t)BK * lb.kstep;
+                    auto hot_seg = [&](int tb, int te, auto tmask_c, auto masked_c) __attribute__((always_inline)) {
+                        for (int t = tb; t < te; ++t) {
+#pragma unroll
+                            for (int p = 0; p < PA; ++p) ra0[p] = ldg4(pa + p * la.pstep);
+#pragma unroll
+                            for (int p = 0; p < PB; ++p) rb0[p] = ldg4(pb + p * lb.pstep);
+                            pa += da; pb += db;
+                            if constexpr (decltype(masked_c)::value) {     // is the tile being staged a diagonal block?
+                                const int64_t k0 = kbeg + (int64_t)(t + 1) * BK;
+                                st_adiag[0] = (aL || aU) && (k0 < m0 + BM) && (k0 + BK > m0);
+                                st_bdiag[0] = (bL || bU) && (k0 < n0 + BN) && (k0 + BK > n0);
+                                st_ad[0] = (int)(k0 - m0);
+                                st_bd[0] = (int)(k0 - n0);
+                            }
+                            ktile(t & 1, true, tmask_c, masked_c, ra0, rb0);
+                            NSGP_LOOP_BARRIER();
+                        }
+                    };
+                    // tiles [p0, p1): the tile they STAGE (t + 1) is no diagonal block -- the bare body, as before; the few
+                    // tiles at either end stage through the masking copy.  Cut [h0, h1) at p0, p1, lo, hi: four copies of
+                    // the loop (MFMAs on / off x masking on / off), picked per stretch.
+                    int p0 = h0, p1 = h1;
+                    {
+                        auto first_k = [&](int t) { return kbeg + (int64_t)(t + 1) * BK; };
+                        // a diagonal block of A covers k in [m0, m0 + BM), of B k in [n0, n0 + BN): staged tiles whose k range meets
+                        // them lie at the ends of the K range (or nowhere)
+                        int64_t dlo = INT64_MAX, dhi = INT64_MIN;                    // k range covered by diagonal blocks
+                        if (aL || aU) { dlo = m0; dhi = m0 + BM; }
+                        if (bL || bU) { if (n0 < dlo) dlo = n0; if (n0 + BN > dhi) dhi = n0 + BN; }
+                        if (dhi > dlo) {
+                            // staged tile t + 1 is plain iff first_k + BK <= dlo or first_k >= dhi.  With both ends possible the plain
+                            // stretch is taken as the longer of the two sides; the rest goes through the masking copy (which is
+                            // correct for every tile).
+                            int below = h0, above = h1;                              // tiles [h0, below) are plain below; [above, h1) plain above
+                            while (below < h1 && first_k(below) + BK <= dlo) ++below;
+                            while (above > h0 && first_k(above - 1) >= dhi) --above;
+                            if (below - h0 >= h1 - above) { p0 = h0; p1 = below; } else { p0 = above; p1 = h1; }
+                        }
+                        p0 = __builtin_amdgcn_readfirstlane(p0);
+                        p1 = __builtin_amdgcn_readfirstlane(p1);
+                    }
+                    int cut[6] = {h0, p0, p1, lo, hi, h1};
+#pragma unroll
+                    for (int a = 1; a < 6; ++a)                                       // insertion sort of six scalars
+#pragma unroll
+                        for (int b = a; b > 0; --b)
+                            if (cut[b] < cut[b - 1]) { const int tmp = cut[b]; cut[b] = cut[b - 1]; cut[b - 1] = tmp; }
+#pragma unroll 1
+                    for (int a = 0; a < 5; ++a) {
+                        const int tb = cut[a], te = cut[a + 1];
+                        if (tb >= te) continue;
+                        const bool active = tb >= lo && te <= hi, plain = tb >= p0 && te <= p1;
+                        if (active && plain) hot_seg(tb, te, std::integral_constant<int, FULLMASK>{}, std::false_type{});
+                        else if (active) hot_seg(tb, te, std::integral_constant<int, FULLMASK>{}, std::true_type{});
+                        else if (plain) hot_seg(tb, te, std::integral_constant<int, 0>{}, std::false_type{});
+                        else hot_seg(tb, te, std::integral_constant<int, 0>{}, std::true_type{});
+                    }
+                    hend = h1;
+                }
+            }
+            if (!ROLL && !DEPTH2 && h1 > h0) {
                 const T* pa = la.cur + (int64_t)(h0 + 1) * BK * la.kstep;
                 const TB* pb = lb.cur + (int64_t)(h0 + 1) * BK * lb.kstep;
                 const int64_t da = (int64_t)BK * la.kstep, db = (int64_t)BK * lb.kstep;
@@ -703,7 +818,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || N
                     if constexpr (KSC != 0) load_ks(kbeg + (int64_t)(t + 1) * BK);
                     pa += da; pb += db;
                     ktile(t & 1, true, std::integral_constant<int, FULLMASK>{}, std::false_type{}, ra0, rb0);
-                    __syncthreads();
+                    NSGP_LOOP_BARRIER();
                 }
                 hend = h1;
             }
@@ -730,14 +845,14 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || N
                         for (int p = 0; p < PB; ++p) rbx[p] = ldg4(pb + p * lb.pstep);
                         pa += da; pb += db;
                         ktile(t & 1, true, std::integral_constant<int, FULLMASK>{}, std::false_type{}, ra0, rb0);   // stores t + 1
-                        __syncthreads();
+                        NSGP_LOOP_BARRIER();
 #pragma unroll
                         for (int p = 0; p < PA; ++p) ra0[p] = ldg4(pa + p * la.pstep);              // tile t + 3 -> set 0
 #pragma unroll
                         for (int p = 0; p < PB; ++p) rb0[p] = ldg4(pb + p * lb.pstep);
                         pa += da; pb += db;
                         ktile((t + 1) & 1, true, std::integral_constant<int, FULLMASK>{}, std::false_type{}, rax, rbx);   // stores t + 2
-                        __syncthreads();
+                        NSGP_LOOP_BARRIER();
                     }
                     hend = t;           // LDS holds tile `hend`; set 0's prefetch of tile hend + 1 is dropped (reloaded below)
                 }
@@ -847,6 +962,25 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (sizeof(T) == 4 || N
     const bool to_slab = g.ksplit > 1;
     T* out = to_slab ? slabs + slice * g.slab + bb * g.M * g.N : Cb;
     const int64_t ldo = to_slab ? g.N : g.ldc;
+    // Interior tile written as it stands (a slab, or alpha * acc with beta = 0, no triangle, no halved diagonal): bare stores
+    // from one base pointer.  The general loop below decides bounds / triangle / beta per element; on the n-wide outputs
+    // (Kzxbar = W^T Abar: every workgroup stores a whole 128 x 128 tile) it took 14 us of a 98 us workgroup, twice the
+    // column-statistics epilogue that stores the same bytes (tools/probes/gemm_stamps.py).
+    const bool plain_tile = (m0 + BM <= g.M) && (n0 + BN <= g.N) &&
+                            (to_slab || (!cL && beta == T(0) && !(g.flags & NSGP_GEMM_C_HALFDIAG)));
+    if (plain_tile) {
+        const T sc = to_slab ? T(1) : alpha;
+        T* o0 = out + (m0 + wm0 + MF::crow_lane(lane)) * ldo + n0 + wn0 + MF::ccol(lane);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < MF::NREG; ++r)       // row = the lane's part (in o0) + a compile-time offset
+                    o0[(int64_t)(i * MT + MF::crow_reg(r)) * ldo + j * MT] = sc * acc[i][j][r];
+        NSGP_STAMP_FLUSH();
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -949,6 +1083,11 @@ template <typename T> Plan make_plan(int64_t M, int64_t N, int64_t K, int64_t nb
     // the tile count at half the work each, so short tiles back-fill behind the long ones.
     p.narrow = p.big && p.ksplit == 1 && !(flags & NSGP_GEMM_C_LOWER) &&
                (flags & (NSGP_GEMM_A_LOWER | NSGP_GEMM_A_UPPER)) && tiles_big <= slots;
+    {   // experiment switch: 128 x 64 tiles (three workgroups per CU) for every single-pass triangular-A launch
+        const char* fn = getenv("NSGP_GEMM_FORCE_NARROW");
+        if (fn && fn[0] == '1' && p.big && p.ksplit == 1 && !(flags & NSGP_GEMM_C_LOWER) &&
+            (flags & (NSGP_GEMM_A_LOWER | NSGP_GEMM_A_UPPER))) p.narrow = 1;
+    }
     return p;
 }
 
@@ -1061,8 +1200,11 @@ int gemm_impl(int64_t M, int64_t N, int64_t K, T alpha, const T* A, int64_t sam,
         constexpr int pb = (MB == 0 && sizeof(T) == 4) ? 1 : Mfma<T>::PAD;
         constexpr size_t lds = 2 * BKc * ((BM_ + pa) + (BN_ + pb)) * sizeof(T);
         auto go = [&](auto kern) {
-            nsgp_opt_in_lds((const void*)kern, lds);
-            hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g, alpha, A, B, beta, C, slabs, ep);
+            // NSGP_GEMM_LDS_EXTRA (bytes): occupancy experiment -- extra dynamic LDS, e.g. 40000 leaves one workgroup per CU
+            static const char* xe = getenv("NSGP_GEMM_LDS_EXTRA");
+            const size_t ldsx = lds + (xe ? (size_t)atoi(xe) : 0);
+            nsgp_opt_in_lds((const void*)kern, ldsx);
+            hipLaunchKernelGGL(kern, grid, dim3(256), ldsx, st, g, alpha, A, B, beta, C, slabs, ep);
         };
         if (whole) go(gemm_kernel<T, BM_, BN_, BKc, MA, MB, EP, KSv, 0, 0>);
         else go(gemm_kernel<T, BM_, BN_, BKc, MA, MB, EP, KSv, 0, 1>);

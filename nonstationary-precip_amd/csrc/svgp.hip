@@ -444,6 +444,208 @@ int kl_bwd_impl(const T* m, const T* Lq, int64_t batch, int64_t M, T gout, T* gm
     return nsgp_launch_status();
 }
 
+// ---- the whole DSVI objective as ONE scalar: two launches forward, two backward -------------------------------------
+// out = ell_scale * sum_s sum_i E_q log N(y_i | f_si, noise) + kl_scale * sum_groups sum_b KL(N(m_b, Lq_b Lq_b^T) || N(0, I))
+// (the caller folds 1/(B S), 1/num_data and the sign into the two scales).  The chain of per-term reductions this replaces
+// cost 6 launches forward and 5 backward for the 2-layer model, ~5 us each under graph replay.
+constexpr int OBJ_MAX_GROUPS = 8;
+template <typename T> struct ObjGroups {
+    const T* m[OBJ_MAX_GROUPS];
+    const T* Lq[OBJ_MAX_GROUPS];
+    T* gm[OBJ_MAX_GROUPS];
+    T* gLq[OBJ_MAX_GROUPS];
+    int batch[OBJ_MAX_GROUPS];
+    int blk0[OBJ_MAX_GROUPS + 1];        // first block of each group in the KL region of a grid
+    int ng;
+};
+
+static inline int64_t kl_blocks(int64_t M) {
+    int64_t nblk = cdiv64(M * M, 1024); if (nblk > 256) nblk = 256; if (nblk < 1) nblk = 1;
+    return nblk;
+}
+
+// blocks [0, S nblk_e): likelihood partials (block (s, x) strides over row s); then, per group and batch element, nblk_k
+// blocks of KL partials (rows x, x + nblk_k, ... of the lower triangle): the arithmetic of gauss_ell_part / kl_part
+template <typename T>
+__global__ __launch_bounds__(256) void dsvi_obj_part_kernel(const T* __restrict__ y, const T* __restrict__ mu,
+                                                            const T* __restrict__ v, const T* __restrict__ noise, int64_t n,
+                                                            int nblk_e, int n_ell, ObjGroups<T> G, int64_t M, int nblk_k,
+                                                            T* __restrict__ part) {
+    __shared__ T lds[4];
+    const int b = (int)blockIdx.x;
+    T acc = T(0);
+    if (b < n_ell) {
+        const int64_t s = b / nblk_e, xb = b % nblk_e;
+        const T s2 = noise[0];
+        const T is2 = T(1) / s2, ls2 = t_log(s2);
+        const T l2pi = T(1.8378770664093454835606594728112);
+        for (int64_t i = xb * 256 + threadIdx.x; i < n; i += (int64_t)nblk_e * 256) {
+            const T d = y[i] - mu[s * n + i];
+            acc += T(-0.5) * ((d * d + v[s * n + i]) * is2 + ls2 + l2pi);
+        }
+    } else {
+        const int kb = b - n_ell;
+        int g = 0;
+        while (g + 1 < G.ng && kb >= G.blk0[g + 1]) ++g;
+        const int rel = kb - G.blk0[g];
+        const int64_t bi = rel / nblk_k, xb = rel % nblk_k;
+        const T* L = G.Lq[g] + bi * M * M;
+        const T* mm = G.m[g] + bi * M;
+        for (int64_t i = xb; i < M; i += nblk_k) {
+            const T* row = L + i * M;
+            for (int64_t j = threadIdx.x; j <= i; j += 256) {
+                const T l = row[j];
+                acc += l * l;
+                if (j == i) acc += mm[i] * mm[i] - T(2) * t_log(l < T(0) ? -l : l);
+            }
+        }
+    }
+    acc = block_sum_256(acc, lds);
+    if (threadIdx.x == 0) part[b] = acc;
+}
+
+// out[0] = ell_scale * sum(part[0 .. n_ell)) + kl_scale * (1/2 sum(part[n_ell .. n_all)) - kl_half_const)
+template <typename T>
+__global__ __launch_bounds__(256) void dsvi_obj_final_kernel(const T* __restrict__ part, int n_ell, int n_all, T ell_scale,
+                                                             T kl_scale, T kl_half_const, T* __restrict__ out) {
+    __shared__ T lds[4];
+    T a = T(0), k = T(0);
+    for (int t = threadIdx.x; t < n_ell; t += 256) a += part[t];
+    for (int t = n_ell + threadIdx.x; t < n_all; t += 256) k += part[t];
+    a = block_sum_256(a, lds);
+    __syncthreads();
+    k = block_sum_256(k, lds);
+    if (threadIdx.x == 0) out[0] = ell_scale * a + kl_scale * (T(0.5) * k - kl_half_const);
+}
+
+// backward: blocks [0, nb_e): gmu / gv; then per group its gLq / gm elements; then (want_gn) S nblk_e blocks of
+// noise-gradient partials.  gout[0] is the upstream gradient of the scalar, read on the device.
+template <typename T>
+__global__ __launch_bounds__(256) void dsvi_obj_bwd_kernel(const T* __restrict__ y, const T* __restrict__ mu,
+                                                           const T* __restrict__ v, const T* __restrict__ noise, int64_t S,
+                                                           int64_t n, T ell_scale, T kl_scale, const T* __restrict__ gout,
+                                                           int nb_e, ObjGroups<T> G, int64_t M, int nb_kl, int nblk_e,
+                                                           T* __restrict__ gmu, T* __restrict__ gv, T* __restrict__ part_gn) {
+    __shared__ T lds[4];
+    const int b = (int)blockIdx.x;
+    const T up = gout[0];
+    if (b < nb_e) {
+        const int64_t idx = (int64_t)b * 256 + threadIdx.x;
+        if (idx >= S * n) return;
+        const T is2 = T(1) / noise[0];
+        const T coef = up * ell_scale;
+        gmu[idx] = coef * (y[idx % n] - mu[idx]) * is2;
+        gv[idx] = T(-0.5) * coef * is2;
+        return;
+    }
+    if (b < nb_e + nb_kl) {
+        const int kb = b - nb_e;
+        int g = 0;
+        while (g + 1 < G.ng && kb >= G.blk0[g + 1]) ++g;
+        const int64_t idx = (int64_t)(kb - G.blk0[g]) * 256 + threadIdx.x;
+        if (idx >= (int64_t)G.batch[g] * M * M) return;
+        const int64_t e = idx % (M * M), bi = idx / (M * M);
+        const int64_t i = e / M, j = e % M;
+        const T go = up * kl_scale;
+        T gg = T(0);
+        if (j <= i) {
+            const T l = G.Lq[g][idx];
+            gg = go * (i == j ? l - T(1) / l : l);
+            if (i == j) G.gm[g][bi * M + i] = go * G.m[g][bi * M + i];
+        }
+        G.gLq[g][idx] = gg;
+        return;
+    }
+    // noise-gradient partials: d/d noise of -1/2 (e / s2 + log s2) = 1/2 (e / s2^2 - 1 / s2)
+    const int rb = b - nb_e - nb_kl;
+    const int64_t s = rb / nblk_e, xb = rb % nblk_e;
+    const T is2 = T(1) / noise[0];
+    T acc = T(0);
+    for (int64_t i = xb * 256 + threadIdx.x; i < n; i += (int64_t)nblk_e * 256) {
+        const T d = y[i] - mu[s * n + i];
+        acc += T(0.5) * ((d * d + v[s * n + i]) * is2 * is2 - is2);
+    }
+    acc = block_sum_256(acc, lds);
+    if (threadIdx.x == 0) part_gn[rb] = acc;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dsvi_obj_gnoise_kernel(const T* __restrict__ part, int nparts, T ell_scale,
+                                                              const T* __restrict__ gout, T* __restrict__ gnoise) {
+    __shared__ T lds[4];
+    T a = T(0);
+    for (int t = threadIdx.x; t < nparts; t += 256) a += part[t];
+    a = block_sum_256(a, lds);
+    if (threadIdx.x == 0) gnoise[0] = gout[0] * ell_scale * a;
+}
+
+template <typename T>
+static int obj_groups(ObjGroups<T>& G, int ngroups, const void* const* m, const void* const* Lq, void* const* gm, void* const* gLq,
+                      const int64_t* batch, int64_t per_batch_blocks_or_elems, bool elems, int64_t M) {
+    G.ng = ngroups;
+    int64_t off = 0;
+    for (int g = 0; g < ngroups; ++g) {
+        if (!m[g] || !Lq[g] || batch[g] < 1) return -1;
+        G.m[g] = (const T*)m[g]; G.Lq[g] = (const T*)Lq[g];
+        G.gm[g] = gm ? (T*)gm[g] : nullptr; G.gLq[g] = gLq ? (T*)gLq[g] : nullptr;
+        if (gm && (!gm[g] || !gLq[g])) return -1;
+        G.batch[g] = (int)batch[g];
+        G.blk0[g] = (int)off;
+        off += elems ? cdiv64(batch[g] * M * M, 256) : batch[g] * per_batch_blocks_or_elems;
+        if (off > 2000000000LL) return -1;
+    }
+    G.blk0[ngroups] = (int)off;
+    return 0;
+}
+
+template <typename T>
+static int dsvi_obj_fwd_impl(const T* y, const T* mu, const T* v, const T* noise, int64_t S, int64_t n, T ell_scale,
+                             int ngroups, const void* const* m, const void* const* Lq, const int64_t* batch, int64_t M,
+                             T kl_scale, T* out, void* ws, size_t wsb, void* stream) {
+    if (!y) return -1; if (!mu) return -2; if (!v) return -3; if (!noise) return -4;
+    if (S < 1 || S > 65535) return -5; if (n < 1) return -6;
+    if (ngroups < 0 || ngroups > OBJ_MAX_GROUPS) return -8; if (ngroups > 0 && (!m || !Lq || !batch)) return -9;
+    if (M < 0) return -12; if (!out) return -14;
+    const int64_t nblk_e = gauss_blocks(n), nblk_k = kl_blocks(M);
+    ObjGroups<T> G{};
+    if (obj_groups<T>(G, ngroups, m, Lq, nullptr, nullptr, batch, nblk_k, false, M)) return -9;
+    const int64_t n_ell = S * nblk_e, n_all = n_ell + G.blk0[ngroups];
+    if (!ws || wsb < (size_t)n_all * sizeof(T)) return -15;
+    int64_t tot_b = 0;
+    for (int g = 0; g < ngroups; ++g) tot_b += batch[g];
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((dsvi_obj_part_kernel<T>), dim3((unsigned)n_all), dim3(256), 0, st, y, mu, v, noise, n, (int)nblk_e,
+                       (int)n_ell, G, M, (int)nblk_k, (T*)ws);
+    hipLaunchKernelGGL((dsvi_obj_final_kernel<T>), dim3(1), dim3(256), 0, st, (const T*)ws, (int)n_ell, (int)n_all, ell_scale,
+                       kl_scale, T(0.5) * T(M) * T(tot_b), out);
+    return nsgp_launch_status();
+}
+
+template <typename T>
+static int dsvi_obj_bwd_impl(const T* y, const T* mu, const T* v, const T* noise, int64_t S, int64_t n, T ell_scale,
+                             int ngroups, const void* const* m, const void* const* Lq, const int64_t* batch, int64_t M,
+                             T kl_scale, const T* gout, T* gmu, T* gv, T* gnoise, void* const* gm, void* const* gLq, void* ws,
+                             size_t wsb, void* stream) {
+    if (!y) return -1; if (!mu) return -2; if (!v) return -3; if (!noise) return -4;
+    if (S < 1 || S > 65535) return -5; if (n < 1) return -6;
+    if (ngroups < 0 || ngroups > OBJ_MAX_GROUPS) return -8; if (ngroups > 0 && (!m || !Lq || !batch)) return -9;
+    if (M < 0) return -12; if (!gout) return -14; if (!gmu) return -15; if (!gv) return -16;
+    if (ngroups > 0 && (!gm || !gLq)) return -18;
+    const int64_t nblk_e = gauss_blocks(n);
+    ObjGroups<T> G{};
+    if (obj_groups<T>(G, ngroups, m, Lq, gm, gLq, batch, 0, true, M)) return -9;
+    const int64_t nb_e = cdiv64(S * n, 256), nb_kl = G.blk0[ngroups], nb_gn = gnoise ? S * nblk_e : 0;
+    if (gnoise && (!ws || wsb < (size_t)nb_gn * sizeof(T))) return -20;
+    if (nb_e + nb_kl + nb_gn > 2000000000LL) return -6;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((dsvi_obj_bwd_kernel<T>), dim3((unsigned)(nb_e + nb_kl + nb_gn)), dim3(256), 0, st, y, mu, v, noise, S, n,
+                       ell_scale, kl_scale, gout, (int)nb_e, G, M, (int)nb_kl, (int)nblk_e, gmu, gv, (T*)ws);
+    if (gnoise)
+        hipLaunchKernelGGL((dsvi_obj_gnoise_kernel<T>), dim3(1), dim3(256), 0, st, (const T*)ws, (int)nb_gn, ell_scale, gout,
+                           gnoise);
+    return nsgp_launch_status();
+}
+
 }  // namespace
 
 template <typename T, typename TP = T>
@@ -678,6 +880,37 @@ int nsgp_kl_whitened_total_bwd_f64(const double* m, const double* Lq, int64_t ba
                                    const double* gout, double* gm, double* gLq, void* stream) {
     if (!gout) return -6;
     return kl_bwd_impl<double>(m, Lq, batch, M, scale, gm, gLq, stream, gout);
+}
+
+size_t nsgp_dsvi_objective_workspace(int64_t S, int64_t n, int64_t M, int64_t total_batch, int elem_size) {
+    if (S < 1 || n < 1) return 0;
+    return (size_t)(S * gauss_blocks(n) + (M > 0 ? total_batch * kl_blocks(M) : 0)) * (size_t)elem_size;
+}
+int nsgp_dsvi_objective_fwd_f32(const float* y, const float* mu, const float* v, const float* noise, int64_t S, int64_t n,
+                                float ell_scale, int ngroups, const void* const* m, const void* const* Lq,
+                                const int64_t* batch, int64_t M, float kl_scale, float* out, void* ws, size_t wsb,
+                                void* stream) {
+    return dsvi_obj_fwd_impl<float>(y, mu, v, noise, S, n, ell_scale, ngroups, m, Lq, batch, M, kl_scale, out, ws, wsb, stream);
+}
+int nsgp_dsvi_objective_fwd_f64(const double* y, const double* mu, const double* v, const double* noise, int64_t S, int64_t n,
+                                double ell_scale, int ngroups, const void* const* m, const void* const* Lq,
+                                const int64_t* batch, int64_t M, double kl_scale, double* out, void* ws, size_t wsb,
+                                void* stream) {
+    return dsvi_obj_fwd_impl<double>(y, mu, v, noise, S, n, ell_scale, ngroups, m, Lq, batch, M, kl_scale, out, ws, wsb, stream);
+}
+int nsgp_dsvi_objective_bwd_f32(const float* y, const float* mu, const float* v, const float* noise, int64_t S, int64_t n,
+                                float ell_scale, int ngroups, const void* const* m, const void* const* Lq,
+                                const int64_t* batch, int64_t M, float kl_scale, const float* gout, float* gmu, float* gv,
+                                float* gnoise, void* const* gm, void* const* gLq, void* ws, size_t wsb, void* stream) {
+    return dsvi_obj_bwd_impl<float>(y, mu, v, noise, S, n, ell_scale, ngroups, m, Lq, batch, M, kl_scale, gout, gmu, gv, gnoise,
+                                    gm, gLq, ws, wsb, stream);
+}
+int nsgp_dsvi_objective_bwd_f64(const double* y, const double* mu, const double* v, const double* noise, int64_t S, int64_t n,
+                                double ell_scale, int ngroups, const void* const* m, const void* const* Lq,
+                                const int64_t* batch, int64_t M, double kl_scale, const double* gout, double* gmu, double* gv,
+                                double* gnoise, void* const* gm, void* const* gLq, void* ws, size_t wsb, void* stream) {
+    return dsvi_obj_bwd_impl<double>(y, mu, v, noise, S, n, ell_scale, ngroups, m, Lq, batch, M, kl_scale, gout, gmu, gv, gnoise,
+                                     gm, gLq, ws, wsb, stream);
 }
 
 }  // extern "C"

@@ -120,6 +120,11 @@ def fused_dsvi_objective(base, approximate_dist_f, target, ell_scale, kl_scale, 
             return None
         pairs.append((vd.variational_mean, vd.chol_variational_covar))
     sign = -1.0 if negate else 1.0                       # negate: the loss -ELBO itself, no separate negation
+    Ms = {Lq.shape[-1] for _, Lq in pairs}
+    if pairs and len(Ms) == 1 and len(pairs) <= 8 and all(m.dtype == mean.dtype for m, _ in pairs):
+        # every layer's KL and the likelihood term in one pair of launches (nsgp_dsvi_objective_fwd / _bwd)
+        flat = [t for pr in pairs for t in pr]
+        return ops.DsviObjectiveFn.apply(target, mean, var, lik.noise, sign * float(ell_scale), -sign * float(kl_scale), *flat)
     total = ops.GaussEllTotalFn.apply(target, mean, var, lik.noise, sign * float(ell_scale))
     for m, Lq in pairs:                                  # each KL term is added into the running scalar by its own kernel
         total = ops.KlWhitenedTotalFn.apply(m, Lq, -sign * float(kl_scale), total)

@@ -1228,6 +1228,76 @@ class KlWhitenedTotalFn(torch.autograd.Function):
         return gm.reshape(ctx.shapes[0]), gL.reshape(ctx.shapes[1]), None, (g if ctx.has_addin else None)
 
 
+class DsviObjectiveFn(torch.autograd.Function):
+    """Scalar  ell_scale * sum_s sum_i E_q log N(y_i | f_si, noise) + kl_scale * sum_g sum_b KL(N(m_gb, Lq_gb Lq_gb^T) || N(0, I))
+    for a list of variational groups (m_g:(b_g,M) or (M,), Lq_g:(b_g,M,M) or (M,M); one per layer, all of the same M):
+    nsgp_dsvi_objective_{fwd,bwd} -- two launches forward, two backward, whatever the number of layers (the chain of
+    GaussEllTotalFn + one KlWhitenedTotalFn per layer it replaces: 2 + 2 per layer forward, 3 + 1 per layer backward).
+    apply(y, mu, v, noise, ell_scale, kl_scale, m_0, Lq_0, m_1, Lq_1, ...)"""
+
+    @staticmethod
+    def _arrays(ms, Ls):
+        ng = len(ms)
+        pm = (ctypes.c_void_p * ng)(*[t.data_ptr() for t in ms])
+        pL = (ctypes.c_void_p * ng)(*[t.data_ptr() for t in Ls])
+        nb = (ctypes.c_int64 * ng)(*[t.shape[0] for t in ms])
+        return ng, pm, pL, nb
+
+    @staticmethod
+    def forward(ctx, y, mu, v, noise, ell_scale, kl_scale, *mL):
+        ref = _chk(y, mu, v, noise, *mL)
+        y, mu, v = _c(y), _c(mu), _c(v)
+        S, n = mu.shape
+        if y.shape != (n,) or v.shape != mu.shape or len(mL) % 2 or len(mL) > 16:
+            raise BackendError('dsvi_objective: shapes')
+        ms, Ls = [], []
+        for m, Lq in zip(mL[0::2], mL[1::2]):
+            m2, L2 = _c(m), _c(Lq)
+            if m2.dim() == 1:
+                m2, L2 = m2.unsqueeze(0), L2.unsqueeze(0)
+            ms.append(m2)
+            Ls.append(L2)
+        M = ms[0].shape[1] if ms else 0
+        if any(m2.shape[1] != M or L2.shape != (m2.shape[0], M, M) for m2, L2 in zip(ms, Ls)):
+            raise BackendError('dsvi_objective: every group must be (b,M) / (b,M,M) with one M')
+        out = torch.empty(1, dtype=ref.dtype, device=ref.device)
+        lib = _lib.load()
+        ws = _ws(lib.nsgp_dsvi_objective_workspace(S, n, M, sum(m2.shape[0] for m2 in ms), ref.element_size()), ref.device)
+        ng, pm, pL, nb = DsviObjectiveFn._arrays(ms, Ls)
+        _lib.call(f'nsgp_dsvi_objective_fwd_{_sfx(ref)}', _p(y), _p(mu), _p(v), _p(noise.reshape(1)), S, n, float(ell_scale), ng,
+                  pm, pL, nb, M, float(kl_scale), _p(out), _p(ws), ws.numel(), _stream())
+        ctx.save_for_backward(y, mu, v, noise, *ms, *Ls)
+        ctx.cfg = (float(ell_scale), float(kl_scale), len(ms), [(m.shape, Lq.shape) for m, Lq in zip(mL[0::2], mL[1::2])])
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        ell_scale, kl_scale, ng, shapes = ctx.cfg
+        y, mu, v, noise, *rest = ctx.saved_tensors
+        ms, Ls = rest[:ng], rest[ng:]
+        S, n = mu.shape
+        M = ms[0].shape[1] if ms else 0
+        gmu, gv = torch.empty_like(mu), torch.empty_like(mu)
+        need_noise = ctx.needs_input_grad[3]
+        gn = torch.empty(1, dtype=mu.dtype, device=mu.device) if need_noise else None
+        gms = [torch.empty_like(m2) for m2 in ms]
+        gLs = []
+        for L2 in Ls:                          # first writer of the gradient bucket's range for Lq (see grad_sink)
+            sink = grad_sink(L2)
+            gLs.append(sink[0] if (sink is not None and not sink[1]) else torch.empty_like(L2))
+        lib = _lib.load()
+        ws = _ws(lib.nsgp_dsvi_objective_workspace(S, n, 0, 0, mu.element_size()), mu.device)
+        _, pm, pL, nb = DsviObjectiveFn._arrays(ms, Ls)
+        pgm = (ctypes.c_void_p * ng)(*[t.data_ptr() for t in gms])
+        pgL = (ctypes.c_void_p * ng)(*[t.data_ptr() for t in gLs])
+        _lib.call(f'nsgp_dsvi_objective_bwd_{_sfx(mu)}', _p(y), _p(mu), _p(v), _p(noise.reshape(1)), S, n, ell_scale, ng, pm, pL,
+                  nb, M, kl_scale, _p(_c(g).reshape(1)), _p(gmu), _p(gv), _p(gn), pgm, pgL, _p(ws), ws.numel(), _stream())
+        grads = []
+        for gm, gL, (sm, sL) in zip(gms, gLs, shapes):
+            grads += [gm.reshape(sm), gL.reshape(sL)]
+        return (None, gmu, gv, gn.reshape(noise.shape) if gn is not None else None, None, None, *grads)
+
+
 class DgpSampleFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mean, var, eps):

@@ -264,3 +264,43 @@ def test_fused_adam_and_flat_bucket_train_the_dgp_like_torch_adam(grads_as_views
         assert abs(a - b) < 1e-3 * abs(b) + 1e-4              # fused flat Adam == torch.optim.Adam
     for pa, pb in zip(model_a.parameters(), model_b.parameters()):
         assert torch.allclose(pa, pb, rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.float64])
+def test_fused_dsvi_objective_equals_the_chain_of_per_term_kernels(dt):
+    """nsgp_dsvi_objective_{fwd,bwd} (ops.DsviObjectiveFn: likelihood term + every layer's KL as one scalar, two launches
+    each way) against the per-term kernels it replaces (GaussEllTotalFn + KlWhitenedTotalFn, themselves held to the oracle by
+    the DSVI tests above): value and every gradient, two groups of different batch size, upstream gradient != 1."""
+    _need_gpu()
+    from nsgp import ops
+    g = torch.Generator().manual_seed(21)
+    S, n, M = 5, 777, 96
+    tol = dict(rtol=2e-5, atol=1e-6) if dt == torch.float32 else dict(rtol=1e-12, atol=1e-13)
+    mk = lambda *shp: torch.randn(*shp, generator=g, dtype=torch.float64).to(dt).cuda()
+    y, mu = mk(n), mk(S, n)
+    v = (mk(S, n).abs() + 0.1)
+    noise = torch.tensor([0.3], dtype=dt, device='cuda')
+    groups = []
+    for b in (2, 1):
+        m = mk(b, M) if b > 1 else mk(M)
+        Lq = (torch.tril(0.1 * mk(b, M, M)) + torch.eye(M, dtype=dt, device='cuda')) if b > 1 else \
+            (torch.tril(0.1 * mk(M, M)) + torch.eye(M, dtype=dt, device='cuda'))
+        groups.append((m, Lq))
+
+    def run(fused):
+        leaves = [t.clone().requires_grad_() for t in (mu, v, noise)] + [t.clone().requires_grad_() for pr in groups for t in pr]
+        mu_, v_, nz_, *mL = leaves
+        if fused:
+            tot = ops.DsviObjectiveFn.apply(y, mu_, v_, nz_, 0.37, -0.011, *mL)
+        else:
+            tot = ops.GaussEllTotalFn.apply(y, mu_, v_, nz_, 0.37)
+            for m_, L_ in zip(mL[0::2], mL[1::2]):
+                tot = ops.KlWhitenedTotalFn.apply(m_, L_, -0.011, tot)
+        (tot * 1.7).backward()
+        return tot.detach(), [t.grad for t in leaves]
+    a, ga = run(True)
+    b_, gb = run(False)
+    assert torch.allclose(a, b_, **tol), (float(a), float(b_))
+    for x, z in zip(ga, gb):
+        assert x.shape == z.shape and torch.allclose(x, z, **tol)
+    assert bool((torch.triu(ga[4], 1) == 0).all())             # strict upper triangle of the Lq gradients is zero

@@ -23,13 +23,13 @@ CAP = 1 << 16
 lib = _lib.load()
 raw = ctypes.CDLL(_lib.LIB_PATH)
 raw.nsgp_debug_gemm_stamps.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
-buf = torch.zeros(CAP * 8, dtype=torch.int64, device='cuda')
+buf = torch.zeros(CAP * 16, dtype=torch.int64, device='cuda')
 assert raw.nsgp_debug_gemm_stamps(ctypes.c_void_p(buf.data_ptr()), CAP) == 0
 
 
 def analyse(name, flops):
     torch.cuda.synchronize()
-    a = buf.cpu().numpy().view(np.uint64).reshape(CAP, 8)
+    a = buf.cpu().numpy().view(np.uint64).reshape(CAP, 16)
     a = a[a[:, 3] != 0]
     if len(a) == 0:
         print(name, ': no records')
@@ -60,6 +60,9 @@ def analyse(name, flops):
         sel = (nt == k) & has_loop
         if sel.any() and k > 0:
             by[int(k)] = (int(sel.sum()), float(np.median(loop[sel] / k)))
+    bar = a[:, 8].astype(np.float64)
+    print(f'    wave 0 waited at the K loop barriers for {bar.sum() / max(loop.sum(), 1):5.1%} of the loop time '
+          f'({np.median(bar[has_loop] / np.maximum(nt[has_loop], 1)):.0f} cycles per K-tile, median)')
     print('    cycles per K-tile in the loop, by K-tiles per workgroup (n workgroups): ' +
           ', '.join(f'{k}: {v[1]:.0f} ({v[0]})' for k, v in sorted(by.items())))
     # per-CU occupancy: union of the workgroups' wall intervals on each CU / launch span; tail = launch end - the CU's last end
@@ -96,6 +99,9 @@ def analyse(name, flops):
 
 
 def run(name, fn, flops):
+    only = os.environ.get('ONLY')
+    if only and not any(o in name for o in only.split(',')):
+        return
     for _ in range(2):
         fn()
     torch.cuda.synchronize()
