@@ -189,6 +189,21 @@ def _timeit(fn, reps=10):
     return e0.elapsed_time(e1) / reps
 
 
+def _eager_and_graphed_ms(step, reps=3, capture=True):
+    """(eager ms, graph-replay ms or None, note): the step launched kernel by kernel, then captured once as a hipGraph and
+    replayed (its optimiser must be capturable; host-side Cholesky checks are skipped while capturing)."""
+    eager = _timeit(step, reps=reps)
+    if not capture:
+        return round(eager, 3), None, None
+    try:
+        from nsgp.graph import GraphedCallable
+        g = GraphedCallable(step, warmup=1)
+        return round(eager, 3), round(_timeit(g, reps=reps), 3), None
+    except Exception as e:                               # a host synchronisation inside the step, an uncapturable torch op ...
+        torch.cuda.synchronize()
+        return round(eager, 3), None, repr(e)[:200]
+
+
 def _b2_inputs(n, device, dt):
     """BASELINE B2 inputs: N = 394 is the real data/uib_spatial.csv (z-scored lon/lat); otherwise a regular lattice,
     z-scored; ell = exp(0.3 N(0,1) + log 0.3) in the reference's (D, N) layout."""
@@ -297,14 +312,19 @@ def b3_sparse_multivariate_step_ms(device):
     model = SparsePSGP(x, y, lik).to(device)
     model.train(); lik.train()
     mll = gpytorch.mlls.ExactMarginalLogLikelihood(lik, model)
-    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=0.01)
+    from nsgp.optim import FusedAdam
+    opt = FusedAdam([p for p in model.parameters() if p.requires_grad], lr=0.01, capturable=True)
 
     def step():
         opt.zero_grad()
         loss = -mll(model(model.train_inputs[0]), model.train_targets)
         loss.backward()
         opt.step()
-    return round(_timeit(step, reps=3), 3)
+    # not captured: the matrix-normal prior's conditional mean (models/sparse_multivariate_gibbs_kernel.py:65-75) goes through
+    # host-side pieces (a 2 x 2 inverse on the CPU, jitter retries that read `info`); capturing it crashed the process
+    eager, graphed, note = _eager_and_graphed_ms(step, capture=False)
+    return {'eager_ms': eager, 'hipgraph_ms': graphed, 'optimizer': 'FusedAdam',
+            'hipgraph_note': 'not captured (host-side pieces in the prior conditional mean)'}
 
 
 def gibbs_chol_ms(device, with_cpu=True):
@@ -318,8 +338,12 @@ def gibbs_chol_ms(device, with_cpu=True):
             out[f'gibbs_build_GBs_{tag}'] = row['build_GBs']
             out[f'potrf_ms_{tag}'] = row['potrf_ms']
             out[f'potrf_TFLOPs_{tag}'] = row['potrf_TFLOPs']
-    out['gibbs_map_step_ms_f64'] = gibbs_map_step_ms(device, 4096)
-    out['b3_sparse_multivariate_step_ms_f32'] = b3_sparse_multivariate_step_ms(device)
+    m = gibbs_map_step_ms(device, 4096)
+    out['gibbs_map_step_ms_f64'] = m['hipgraph_ms'] if m['hipgraph_ms'] is not None else m['eager_ms']
+    out['gibbs_map_step_f64'] = m
+    b3 = b3_sparse_multivariate_step_ms(device)
+    out['b3_sparse_multivariate_step_ms_f32'] = b3['hipgraph_ms'] if b3['hipgraph_ms'] is not None else b3['eager_ms']
+    out['b3_sparse_multivariate_step_f32'] = b3
     return out
 
 
@@ -350,24 +374,18 @@ def gibbs_map_step_ms(device, n):
         p.requires_grad = False
     model.train()
     lik.train()
-    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=0.01)
     mll = gpytorch.mlls.ExactMarginalLogLikelihood(lik, model)
     xd, yd = model.train_inputs[0], model.train_targets
+    # float64 model: FusedAdam keeps float32 buckets, so this step uses torch's own capturable Adam
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=0.01, capturable=True, foreach=True)
 
     def step():
-        opt.zero_grad()
+        opt.zero_grad(set_to_none=True)
         loss = -mll(model(xd), yd)
         loss.backward()
         opt.step()
-    step()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(3):
-        step()
-    e1.record()
-    torch.cuda.synchronize()
-    return round(e0.elapsed_time(e1) / 3, 3)
+    eager, graphed, note = _eager_and_graphed_ms(step)
+    return {'eager_ms': eager, 'hipgraph_ms': graphed, **({'hipgraph_note': note} if note else {})}
 
 
 def cpu_baseline_cfg5(rows=1024, M=2048, S=10, n_data=1_000_000, seconds_budget=30.0):

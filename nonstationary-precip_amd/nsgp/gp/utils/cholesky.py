@@ -22,8 +22,14 @@ class NotPSDError(RuntimeError):
     pass
 
 
+def _capturing(t):
+    return t.is_cuda and torch.cuda.is_current_stream_capturing()
+
+
 def psd_safe_cholesky(A, upper=False, out=None, jitter=None, max_tries=3):
     L, info = ops.potrf(A)
+    if _capturing(A):                                   # hipGraph capture: no host read of `info`, no retry ladder (the
+        return L.transpose(-1, -2) if upper else L      # eager warm-up steps before the capture went through the checks)
     if int(info.max().item()) != 0:                     # the reference syncs here too (torch raises)
         if torch.isnan(A).any():
             raise NanError(f'cholesky_cpu: {int(torch.isnan(A).sum())} of {A.numel()} elements are NaN')
@@ -57,7 +63,7 @@ def chol_inv_safe(K, jitter=None, max_tries=3):
     its kernel on the TIME column of inducing points that share time stamps, a singular Kzz.
     One host sync per call (reading `info`), like the reference's exception-driven retry."""
     W, info = ops.chol_inv(K)
-    if int(info.max().item()) == 0:
+    if _capturing(K) or int(info.max().item()) == 0:     # (capture: see psd_safe_cholesky)
         return W
     if torch.isnan(K).any():
         raise NanError(f'cholesky: {int(torch.isnan(K).sum())} of {K.numel()} elements are NaN')

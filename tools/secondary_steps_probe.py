@@ -18,6 +18,6 @@ if __name__ == '__main__':
     dev = torch.device('cuda', 0)
     torch.cuda.set_device(0)
     if 'map' in which:
-        print('gibbs_map_step_ms_f64 (N=4096):', bench.gibbs_map_step_ms(dev, 4096), flush=True)
+        print('gibbs_map_step f64 (N=4096):', bench.gibbs_map_step_ms(dev, 4096), flush=True)
     if 'b3' in which:
-        print('b3_sparse_multivariate_step_ms_f32:', bench.b3_sparse_multivariate_step_ms(dev), flush=True)
+        print('b3_sparse_multivariate_step f32:', bench.b3_sparse_multivariate_step_ms(dev), flush=True)
