@@ -103,18 +103,18 @@ def gemm_source_sha():
 
 def gemm_traffic(world, share):
     """`traffic`: average L2<->fabric bytes per f32 GEMM launch of a step, from the committed rocprofv3 PMC passes of
-    this same single-GPU workload (tools/gemm_traffic.py -> profiles/r02/gemm_traffic.json).  PMC counters cannot be
+    this same single-GPU workload (tools/gemm_traffic.py -> profiles/r03/gemm_traffic.json).  PMC counters cannot be
     read from inside the process, so this is the recorded measurement, not a live one; it is reported only while the
     GEMM source still hashes to what the passes were taken on (null otherwise, and for N > 1)."""
-    path = os.path.join(ROOT, 'profiles', 'r02', 'gemm_traffic.json')
+    path = os.path.join(ROOT, 'profiles', 'r03', 'gemm_traffic.json')
     if world != 1 or share != 1 or not os.path.exists(path):
         return {'traffic': None}
     try:
         d = json.load(open(path))
         if d.get('gemm_source_sha') != gemm_source_sha():
-            return {'traffic': None, 'traffic_note': 'profiles/r02/gemm_traffic.json is stale (gemm.hip changed since the PMC passes)'}
+            return {'traffic': None, 'traffic_note': 'profiles/r03/gemm_traffic.json is stale (gemm.hip changed since the PMC passes)'}
         return {'traffic': round(float(d['bytes_per_launch'])), 'traffic_unit': 'bytes per launch (FETCH_SIZE x2 + '
-                'WRITE_SIZE, incl. Infinity-Cache hits)', 'traffic_source': 'profiles/r02/gemm_traffic.json',
+                'WRITE_SIZE, incl. Infinity-Cache hits)', 'traffic_source': 'profiles/r03/gemm_traffic.json',
                 'algorithmic_bytes_per_launch': d.get('algorithmic_bytes_per_launch')}
     except (OSError, ValueError, KeyError):
         return {'traffic': None}

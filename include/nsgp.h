@@ -290,6 +290,11 @@ int nsgp_svgp_tri_gemm_colstats_f64acc(const double* W, const float* X, const fl
 int nsgp_svgp_tri_gemm_colstats_f64acc_b64(const double* W, const double* X64, const float* rowvec, int64_t batch, int64_t M,
                                            int64_t n, float* Y, double* part_dot, double* part_sq, int64_t part_rows,
                                            void* stream);
+/* The same with float32 partials (layout and meaning of nsgp_svgp_tri_gemm_colstats_f64acc): for layers whose second
+ * projection stays on the float32 kernel (settings.hidden_var_f64 off). */
+int nsgp_svgp_tri_gemm_colstats_f64acc_b64p32(const double* W, const double* X64, const float* rowvec, int64_t batch, int64_t M,
+                                              int64_t n, float* Y, float* part_dot, float* part_sq, int64_t part_rows,
+                                              void* stream);
 /* The second projection of such a layer, Y[b] = L[b]^T X[b] (L: float64 copy of the stored lower-triangular Lq; X = the float32
  * A), accumulated in float64: its variance is os + colsum(C^2 - A^2), and float32 accumulation of the 1024-term dot products
  * of C is not consistent with the float64 colsum(A^2); both reach the next layer through sqrt(var) eps.  part_sq: the

@@ -1438,6 +1438,12 @@ int nsgp_svgp_tri_gemm_colstats_f64acc_b64(const double* W, const double* X64, c
                                          reinterpret_cast<float*>(part_sq), part_rows, stream, nullptr, X64, 0, 1);
 }
 
+int nsgp_svgp_tri_gemm_colstats_f64acc_b64p32(const double* W, const double* X64, const float* rowvec, int64_t batch, int64_t M,
+                                              int64_t n, float* Y, float* part_dot, float* part_sq, int64_t part_rows,
+                                              void* stream) {
+    if (!X64) return -2;
+    return tri_gemm_colstats_f64acc_impl(W, nullptr, rowvec, batch, M, n, Y, part_dot, part_sq, part_rows, stream, nullptr, X64, 0, 0);
+}
 int nsgp_svgp_tri_gemm_colstats_f64acc_t(const double* L, const float* X, int64_t batch, int64_t M, int64_t n, float* Y,
                                          double* part_sq, int64_t part_rows, void* stream) {
     return tri_gemm_colstats_f64acc_impl(L, X, nullptr, batch, M, n, Y, nullptr, reinterpret_cast<float*>(part_sq), part_rows,

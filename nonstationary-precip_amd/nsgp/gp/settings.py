@@ -149,6 +149,17 @@ class hidden_kzx_f64(_feature_flag):
     _state = True
 
 
+class hidden_var_f64(_value_context):
+    """With hidden_kzx_f64: also run the SECOND projection C = Lq^T A of such a layer on the float64-accumulating kernel, with
+    float64 column-statistic partials, so that its variance os + colsum(C^2 - A^2) -- a difference of two O(os) sums that
+    cancels to << os once q(u) has trained -- carries no float32 partial-sum rounding (4e-8 absolute = 5e-5 of a small
+    variance, which reaches the next layer through sqrt(var) eps: output mean 5.4e-5 instead of 2.5e-5 after 1000 steps).
+    True / False, or 'auto' (default): on where the layer sees at most 8192 points per output GP -- the first hidden layer
+    of a deep GP (its inputs are the minibatch); deeper hidden layers see S x minibatch points, where the float64 product
+    costs as much as the whole float32 layer (+12 % on a BASELINE configs[4] step)."""
+    _value = 'auto'
+
+
 class check_mvn_cholesky(_feature_flag):
     """On (default): MultivariateNormal.log_prob reads the Cholesky `info` of its dense covariance (one host sync) and
     follows psd_safe_cholesky -- jitter retries with a NumericalWarning, then NotPSDError -- instead of returning a NaN

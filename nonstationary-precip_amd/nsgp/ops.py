@@ -658,14 +658,15 @@ def svgp_project(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None, kern
         W64f = _c(W64f)
         T64 = int(lib.nsgp_svgp_f64acc_tiles_for(M, n, batch))    # 128-row tiles, 64-row ones for small grids
         p64 = b64 and Lq64 is not None            # both projections on the float64-accumulating kernel: float64 partials
-        if b64 and not p64:
-            raise BackendError('svgp_project: Kzx64 comes with Lq64 (both projections accumulate in float64)')
         T32, T = T, (T64 if p64 else max(T, T64))
         # tile rows one of the two kernels does not fill (their tile heights differ for some shapes) stay zero
         part = (torch.zeros if (T64 != T32 and not p64) else torch.empty)(
             (3, batch, max(T, 1), n), dtype=torch.float64 if p64 else ref.dtype, device=ref.device)
-        if b64:
+        if b64 and p64:
             _timed(lambda: _lib.call('nsgp_svgp_tri_gemm_colstats_f64acc_b64', _p(W64f), _p(Kzx64), _p(m), batch, M, n, _p(A),
+                                     _p(part[0]), _p(part[1]), T, st), flops, 'f64acc')
+        elif b64:                                 # float64 Kzx, float32 partials (the second projection stays float32)
+            _timed(lambda: _lib.call('nsgp_svgp_tri_gemm_colstats_f64acc_b64p32', _p(W64f), _p(Kzx64), _p(m), batch, M, n, _p(A),
                                      _p(part[0]), _p(part[1]), T, st), flops, 'f64acc')
         elif fused:
             _timed(lambda: _lib.call('nsgp_svgp_kzx_gemm_colstats_f64acc', _p(W64f), _p(kZ), _p(kx),

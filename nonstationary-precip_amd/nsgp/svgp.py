@@ -189,11 +189,13 @@ class SVGPLayerFn(torch.autograd.Function):
         # copy) for the float64-accumulating projection; its float32 Kzx is only needed by the backward, which builds it
         Kzx64 = Lq64 = None
         if kzx_f64 and fp == 'f32' and W64f is not None and not fuse:
-            src = [x.detach(), Z.detach(), ls.detach(), os_.detach(), Lq.detach()]
+            hv = settings.hidden_var_f64.value()
+            var64 = (x.shape[-2] <= 8192) if hv == 'auto' else bool(hv)
+            src = [x.detach(), Z.detach(), ls.detach(), os_.detach()] + ([Lq.detach()] if var64 else [])
             dst = [torch.empty(t.shape, dtype=torch.float64, device=t.device) for t in src]
             torch._foreach_copy_(dst, src)
             Kzx64 = ops.rbf_build(dst[1], dst[0], dst[2], dst[3])
-            Lq64 = dst[4]                     # C = Lq^T A accumulates in float64 too (the variance's cancellation)
+            Lq64 = dst[4] if var64 else None  # C = Lq^T A accumulates in float64 too (the variance's cancellation)
         Kzx = None if (fuse or Kzx64 is not None) else ops.rbf_build(Z, x, ls, os_)                     # (b,M,n)
         if x.dtype == torch.float32 and fp in ('bf16', 'bf16_all') and Z.shape[-2] % 8 == 0:
             # BASELINE configs[4]'s "bf16 forward": C = Lq^T A on the bf16 matrix cores; 'bf16_all' also A = W Kzx
