@@ -36,6 +36,8 @@ M_INDUCING, S_SAMPLES, BATCH, N_DATA, SEED = 1024, 10, 4096, 100_000, 173
 MFMA_F32_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 MFMA_F64_PEAK_TFLOPS = 78.6           # v_mfma_f64_16x16x4_f64: half the f32 matrix rate
 MFMA_BF16_PEAK_TFLOPS = 2500.0        # v_mfma_f32_32x32x16_bf16, dense (MI355X_MICROARCH.md)
+MFMA_I8_PEAK_TOPS = 5000.0            # v_mfma_i32_32x32x32_i8: 2x the bf16 rate per clock (same guide)
+I8_PLANE_PRODUCTS = 14                # digit-plane products per multiply-add of the int8 projection (csrc/gemm_i8.hip; 15 with 5 Kzx planes)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -455,6 +457,10 @@ def main_cfg5(args):
                                    'achieved': r['f64acc_gemm_TFLOPs'], 'peak': MFMA_F64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                    'frac': round(r['f64acc_gemm_TFLOPs'] / MFMA_F64_PEAK_TFLOPS, 4)}
                                   if r['f64acc_gemm_launches'] else None),
+            'i8_projection': ({'ms_per_step': r['i8_gemm_ms_per_step'], 'launches_per_step': r['i8_gemm_launches'],
+                               'achieved': round(I8_PLANE_PRODUCTS * r['i8_gemm_TFLOPs_f64eq'] / 1e0, 1), 'peak': MFMA_I8_PEAK_TOPS,
+                               'unit': 'TOP/s (int8)', 'frac': round(I8_PLANE_PRODUCTS * r['i8_gemm_TFLOPs_f64eq'] / MFMA_I8_PEAK_TOPS, 4),
+                               'f64_equivalent_TFLOPs': r['i8_gemm_TFLOPs_f64eq']} if r.get('i8_gemm_launches') else None),
             'bf16_projection': ({'ms_per_step': r['bf16_gemm_ms_per_step'], 'launches_per_step': r['bf16_gemm_launches'],
                                  'achieved': r['bf16_gemm_TFLOPs'], 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                  'frac': round(r['bf16_gemm_TFLOPs'] / MFMA_BF16_PEAK_TFLOPS, 4)}
@@ -755,6 +761,7 @@ def main():
         gemm_ms, gemm_flops, gemm_launches = timer.summary(torch.float32)
         g64_ms, g64_flops, g64_launches = timer.summary(torch.float64)
         acc_ms, acc_flops, acc_launches = timer.summary('f64acc')
+        i8_ms, i8_flops, i8_launches = timer.summary('i8')
         ops.set_gemm_timer(None)
 
     result = None
@@ -810,6 +817,16 @@ def main():
                                    'achieved': round(acc_flops / (acc_ms * 1e-3) / 1e12, 2), 'peak': MFMA_F64_PEAK_TFLOPS,
                                    'unit': 'TFLOP/s', 'frac': round(acc_flops / (acc_ms * 1e-3) / 1e12 / MFMA_F64_PEAK_TFLOPS, 4)}
                                   if acc_launches else None),
+            # the same projection on the int8 matrix cores (settings.whiten_matmul_i8, default): exact digit-plane products.
+            # `achieved` counts the int8 operations actually issued (14 plane products per multiply-add of the float64
+            # product it replaces; 15 for layers with five Kzx planes are counted as 14) against the 5 POP/s dense int8 peak;
+            # `f64_equivalent_TFLOPs` is the float64 product's flops over the same time (the float64 MFMA peak is 78.6)
+            'i8_projection': ({'ms_per_step': round(i8_ms / nprof, 3), 'launches_per_step': i8_launches // nprof,
+                               'algorithmic_gflop_per_step': round(i8_flops / nprof / 1e9, 2),
+                               'achieved': round(I8_PLANE_PRODUCTS * i8_flops / (i8_ms * 1e-3) / 1e12, 1), 'peak': MFMA_I8_PEAK_TOPS,
+                               'unit': 'TOP/s (int8)', 'frac': round(I8_PLANE_PRODUCTS * i8_flops / (i8_ms * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS, 4),
+                               'f64_equivalent_TFLOPs': round(i8_flops / (i8_ms * 1e-3) / 1e12, 2)}
+                              if i8_launches else None),
         }
         if world == 1:
             if not args.no_build_chol:

@@ -307,6 +307,29 @@ int nsgp_svgp_colstats_finalize_affine_p64_f32(const double* part_dot, const dou
                                                const float* x, int64_t x_batch_stride, int64_t D, const float* w,
                                                int64_t w_batch_stride, const float* c, int64_t c_batch_stride, float* mean,
                                                float* var, void* stream);
+/* The same projection A = W Kzx on the INT8 matrix cores, to better than float32 accuracy (csrc/gemm_i8.hip): W and Kzx are
+ * cut into signed 7-bit digit planes against a per-row / per-GP power-of-two scale (5 planes of W, 4 of Kzx, the latter
+ * evaluated in float64 from the float32 kernel inputs), the 14 plane products with a + b <= 4 are accumulated EXACTLY in
+ * int32 on v_mfma_i32_32x32x32_i8 and combined in float64, rounded once to float32: the reference's float64 triangular solve
+ * (behind /root/reference/models/dgps.py:44-51) at 64x the float64 MFMA rate per multiply-add.
+ *   nsgp_i8_slice_w_f64:  W:(batch,M,M) float64, lower triangle used -> Wd (nsgp_i8_w_planes_bytes), wscale:(batch,M)
+ *   nsgp_i8_rbf_build_f32: Z:(batch,M,D), x:(n,D) (x_batch_stride 0) or (batch,n,D), ls:(batch,D), os:(batch,), D <= 4
+ *                          -> Kd (nsgp_i8_k_planes_bytes), kscale:(batch,)
+ *   nsgp_svgp_tri_gemm_colstats_i8: Y:(batch,M,n) float32 and the column-statistic partials of
+ *       nsgp_svgp_tri_gemm_colstats (nsgp_i8_tiles(M) = ceil(M/128) tile rows; float32, or float64 with partials_f64 != 0),
+ *       taken from the float64 values.  rowvec may be NULL (then part_dot is not written).
+ * `planes` = digit planes of Kzx: 4 (28 bits below os: 1e-6 of max|A| at kappa ~ 1e6) or 5 (35 bits, 15 plane products: layers
+ * whose output is the next layer's input).  nsgp_i8_supported(M): 1 <= M <= 4096. */
+int nsgp_i8_supported(int64_t M);
+size_t nsgp_i8_w_planes_bytes(int64_t batch, int64_t M);
+size_t nsgp_i8_k_planes_bytes(int64_t batch, int64_t M, int64_t n, int planes);
+size_t nsgp_i8_tiles(int64_t M);
+int nsgp_i8_slice_w_f64(const double* W, int64_t batch, int64_t M, void* Wd, double* wscale, void* stream);
+int nsgp_i8_rbf_build_f32(const float* Z, const float* x, int64_t x_batch_stride, const float* ls, const float* os,
+                          int64_t batch, int64_t M, int64_t n, int D, int planes, void* Kd, double* kscale, void* stream);
+int nsgp_svgp_tri_gemm_colstats_i8(const void* Wd, const double* wscale, const void* Kd, const double* kscale,
+                                   int planes, const float* rowvec, int64_t batch, int64_t M, int64_t n, float* Y,
+                                   void* part_dot, void* part_sq, int64_t part_rows, int partials_f64, void* stream);
 /* "bf16 forward" of BASELINE configs[4] (3-layer DSVI DeepGP, M = 2048: bf16 forward / fp32 Cholesky panels): the two
  * forward projections A = W Kzx, C = Lq^T A of a whitened SVGP layer (gpytorch VariationalStrategy.forward behind
  * /root/reference/models/dgps.py:44-51, driven by :92-98) on v_mfma_f32_32x32x16_bf16 -- bf16 operands, float32

@@ -137,6 +137,17 @@ class whiten_matmul_f64(_feature_flag):
     _state = True
 
 
+class whiten_matmul_i8(_feature_flag):
+    """On: the whitened projection A = L^-1 Kzx of a float32 SVGP layer runs on the INT8 matrix cores as an exact
+    digit-plane product (csrc/gemm_i8.hip: 5 signed 7-bit planes of the float64 W x 4 planes of Kzx evaluated in float64,
+    14 plane products accumulated exactly in int32, combined in float64, rounded once) -- 9.5e-7 of max|A| against the
+    float64 product at kappa(Kzz) ~ 1e6, where float64 accumulation of a float32 Kzx gives 5.6e-6 and float32 accumulation
+    6.6e-5 -- at 64x the float64 MFMA rate per multiply-add.  Takes precedence over whiten_matmul_f64's float64 MFMA product
+    and over hidden_kzx_f64 (its Kzx digits already come from a float64 evaluation); needs the float64 W of the whitening
+    chain, D <= 4 input dimensions and M <= 4096.  Off: the float64-accumulating product (round 2's arithmetic)."""
+    _state = True
+
+
 class hidden_kzx_f64(_feature_flag):
     """On (default): a float32 layer whose output is the NEXT layer's input (a DeepGPLayer with output_dims, i.e. every layer
     of a deep GP but the last) builds its Kzx in float64 and feeds it to the float64-accumulating projection

@@ -609,7 +609,26 @@ def svgp_kzx_fusable(W64f, Z, x, n):
     return bool(_lib.load().nsgp_svgp_kzx_gemm_supported(_p(W64f), M, n, batch, D))
 
 
-def svgp_project(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None, kernel_inputs=None, Kzx64=None, Lq64=None):
+def _project_a_i8(W64f, kZ, kx, kls, kos, m, A, part_dot, part_sq, T, p64, planes, flops):
+    """A = W Kzx as the exact int8 digit-plane product (csrc/gemm_i8.hip): digit planes of W and of Kzx (evaluated in
+    float64 from Z, x, ls, os), then the product with its column-statistic partials (T tile rows per batch element)."""
+    lib = _lib.load()
+    batch, M, D = kZ.shape
+    n = kx.shape[-2]
+    dev, st = A.device, _stream()
+    Wd = torch.empty(int(lib.nsgp_i8_w_planes_bytes(batch, M)), dtype=torch.uint8, device=dev)
+    Kd = torch.empty(int(lib.nsgp_i8_k_planes_bytes(batch, M, n, planes)), dtype=torch.uint8, device=dev)
+    wsc = torch.empty((batch, M), dtype=torch.float64, device=dev)
+    ksc = torch.empty((batch,), dtype=torch.float64, device=dev)
+    _lib.call('nsgp_i8_slice_w_f64', _p(W64f), batch, M, _p(Wd), _p(wsc), st)
+    _lib.call('nsgp_i8_rbf_build_f32', _p(kZ), _p(kx), n * D if kx.dim() == 3 else 0, _p(kls), _p(kos), batch, M, n, D,
+              planes, _p(Kd), _p(ksc), st)
+    _timed(lambda: _lib.call('nsgp_svgp_tri_gemm_colstats_i8', _p(Wd), _p(wsc), _p(Kd), _p(ksc), planes, _p(m), batch, M, n,
+                             _p(A), _p(part_dot), _p(part_sq), T, 1 if p64 else 0, st), flops, 'i8')
+
+
+def svgp_project(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None, kernel_inputs=None, Kzx64=None, Lq64=None,
+                 i8_inputs=None, i8_planes=4):
     """Fused K6 forward: A = W Kzx, C = Lq^T A (triangular MFMA GEMMs) with the column statistics reduced in
     the GEMM epilogues.  W, Lq:(b,M,M) lower; Kzx:(b,M,n); m:(b,M); base:(b,).
     Returns A, C, mean = A^T m (+ the affine prior mean x w + c, `affine` = (x, w, c)), var = base + base_add +
@@ -618,6 +637,21 @@ def svgp_project(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None, kern
     (nsgp_svgp_tri_gemm_colstats_f64acc: the reference's float64 solve); W itself (float32) is only used by the backward.
     kernel_inputs=(Z, x, ls, os) with Kzx=None (and W64f, `svgp_kzx_fusable`): Kzx is never materialised, its tiles are
     generated inside the loader of the first product from Z:(b,M,D), x:(n,D) or (b,n,D), ls:(b,D), os:(b,)."""
+    i8 = i8_inputs is not None
+    if i8:
+        # A = W Kzx on the int8 matrix cores (csrc/gemm_i8.hip): exact int32 accumulation of 14 digit-plane products of the
+        # float64 W and of Kzx evaluated in float64 from (Z, x, ls, os); Kzx itself is never materialised in the forward pass
+        if Kzx is not None or Kzx64 is not None or kernel_inputs is not None or W64f is None:
+            raise BackendError('svgp_project: i8_inputs=(Z, x, ls, os) comes with W64f and without Kzx / Kzx64 / kernel_inputs')
+        kZ, kx, kls, kos = i8_inputs
+        ref = _chk(W, Lq, m, base, kZ, kx, kls, kos)
+        kZ, kx, kls, kos = _c(kZ), _c(kx), _c(kls), _c(kos.reshape(-1))
+        W, Lq, m, base = _c(W), _c(Lq), _c(m), _c(base.reshape(-1))
+        batch, M, D = kZ.shape
+        n = kx.shape[-2]
+        if ref.dtype != torch.float32 or kx.shape[-1] != D or (kx.dim() == 3 and kx.shape[0] != batch) \
+                or kls.shape != (batch, D) or kos.shape != (batch,) or D > 4 or not _lib.load().nsgp_i8_supported(M):
+            raise BackendError('svgp_project: i8_inputs shapes (float32 layer, D <= 4, M <= 4096)')
     b64 = Kzx64 is not None
     if b64:
         if Kzx is not None or W64f is None or Kzx64.dtype != torch.float64 or Kzx64.dim() != 3:
@@ -627,7 +661,7 @@ def svgp_project(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None, kern
             raise BackendError('svgp_project: Kzx64 device')
         W, Kzx64, Lq, m, base = _c(W), _c(Kzx64), _c(Lq), _c(m), _c(base.reshape(-1))
         batch, M, n = Kzx64.shape
-    fused = Kzx is None and not b64
+    fused = Kzx is None and not b64 and not i8
     if fused:
         if kernel_inputs is None or W64f is None:
             raise BackendError('svgp_project: Kzx=None needs kernel_inputs and W64f')
@@ -639,7 +673,7 @@ def svgp_project(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None, kern
         n = kx.shape[-2]
         if kx.shape[-1] != D or (kx.dim() == 3 and kx.shape[0] != batch) or kls.shape != (batch, D) or kos.shape != (batch,):
             raise BackendError('svgp_project: kernel_inputs shapes')
-    elif not b64:
+    elif not b64 and not i8:
         ref = _chk(W, Kzx, Lq, m, base)
         W, Kzx, Lq, m, base = _c(W), _c(Kzx), _c(Lq), _c(m), _c(base.reshape(-1))
         batch, M, n = Kzx.shape
@@ -656,13 +690,17 @@ def svgp_project(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None, kern
                 or W64f.device != ref.device:
             raise BackendError('svgp_project: W64f must be the float64 (b,M,M) W of a float32 layer')
         W64f = _c(W64f)
-        T64 = int(lib.nsgp_svgp_f64acc_tiles_for(M, n, batch))    # 128-row tiles, 64-row ones for small grids
-        p64 = b64 and Lq64 is not None            # both projections on the float64-accumulating kernel: float64 partials
+        T64 = int(lib.nsgp_i8_tiles(M)) if i8 else int(lib.nsgp_svgp_f64acc_tiles_for(M, n, batch))   # tile rows of product 1
+        if i8 and Lq64 is not None:               # product 2 on the float64-accumulating kernel: ITS tile rows for part[2]
+            T64 = max(T64, int(lib.nsgp_svgp_f64acc_tiles_for(M, n, batch)))
+        p64 = (b64 or i8) and Lq64 is not None    # both projections accumulate in float64: float64 partials
         T32, T = T, (T64 if p64 else max(T, T64))
         # tile rows one of the two kernels does not fill (their tile heights differ for some shapes) stay zero
-        part = (torch.zeros if (T64 != T32 and not p64) else torch.empty)(
+        part = (torch.zeros if ((T64 != T32 and not p64) or (i8 and p64)) else torch.empty)(
             (3, batch, max(T, 1), n), dtype=torch.float64 if p64 else ref.dtype, device=ref.device)
-        if b64 and p64:
+        if i8:
+            _project_a_i8(W64f, kZ, kx, kls, kos, m, A, part[0], part[1], T, p64, 5 if i8_planes == 5 else 4, flops)
+        elif b64 and p64:
             _timed(lambda: _lib.call('nsgp_svgp_tri_gemm_colstats_f64acc_b64', _p(W64f), _p(Kzx64), _p(m), batch, M, n, _p(A),
                                      _p(part[0]), _p(part[1]), T, st), flops, 'f64acc')
         elif b64:                                 # float64 Kzx, float32 partials (the second projection stays float32)
@@ -680,8 +718,8 @@ def svgp_project(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None, kern
         _timed(lambda: _lib.call(f'nsgp_svgp_tri_gemm_colstats_{sfx}', _p(W), 0, _p(Kzx), _p(m), batch, M, n, _p(A),
                                  _p(part[0]), _p(part[1]), st), flops, ref.dtype)
     if Lq64 is not None:                      # C = Lq^T A accumulated in float64 (layers that feed the next layer)
-        if W64f is None or not b64 or Lq64.dtype != torch.float64 or Lq64.shape != (batch, M, M) or Lq64.device != ref.device:
-            raise BackendError('svgp_project: Lq64 must be the float64 (b,M,M) copy of Lq (with W64f and Kzx64)')
+        if W64f is None or not (b64 or i8) or Lq64.dtype != torch.float64 or Lq64.shape != (batch, M, M) or Lq64.device != ref.device:
+            raise BackendError('svgp_project: Lq64 must be the float64 (b,M,M) copy of Lq (with W64f and Kzx64 / i8_inputs)')
         _timed(lambda: _lib.call('nsgp_svgp_tri_gemm_colstats_f64acc_t', _p(_c(Lq64)), _p(A), batch, M, n, _p(C), _p(part[2]),
                                  T, st), flops, 'f64acc')
     else:
@@ -700,7 +738,7 @@ def svgp_project(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None, kern
     return A, C, mean, var
 
 
-def svgp_project_bf16(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None, kernel_inputs=None):
+def svgp_project_bf16(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None, kernel_inputs=None, i8_inputs=None):
     """BASELINE configs[4]'s "bf16 forward": the forward projections of a float32 SVGP layer with bf16 matrix-core products
     (bf16 operands, float32 accumulation, float32 A / C; csrc/gemm_bf16.hip), column statistics in the epilogues.
 
@@ -711,11 +749,18 @@ def svgp_project_bf16(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None,
     kernel_inputs=(Z, x, ls, os) (forward_precision('bf16_all')): BOTH products in bf16, Kxz written in bf16 by the build
         kernel (nsgp_rbf_build_t_bf16) -- configs[4] to the letter; a throughput figure, not a usable numerical mode.
     Returns A, C, mean, var (float32).  M must be a multiple of 8."""
-    ref = _chk(Kzx, Lq, m, base)
+    ref = _chk(Lq, m, base, Kzx)
     if ref.dtype != torch.float32:
         raise BackendError('svgp_project_bf16: float32 layers only')
-    Kzx, Lq, m, base = _c(Kzx), _c(Lq), _c(m), _c(base.reshape(-1))
-    batch, M, n = Kzx.shape
+    Lq, m, base = _c(Lq), _c(m), _c(base.reshape(-1))
+    if Kzx is None:                          # mode 'bf16' with product 1 on the int8 cores: Kzx is never materialised
+        if i8_inputs is None or W64f is None or kernel_inputs is not None:
+            raise BackendError('svgp_project_bf16: Kzx=None needs i8_inputs and W64f (mode bf16)')
+        batch, M = i8_inputs[0].shape[0], i8_inputs[0].shape[1]
+        n = i8_inputs[1].shape[-2]
+    else:
+        Kzx = _c(Kzx)
+        batch, M, n = Kzx.shape
     if M % 8 != 0:
         raise BackendError('svgp_project_bf16: M must be a multiple of 8')
     if Lq.shape != (batch, M, M) or m.shape != (batch, M) or base.shape != (batch,):
@@ -735,14 +780,18 @@ def svgp_project_bf16(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None,
         # e.g. M = 1024, n = 4032, b = 1 gives Tf = 8 but T64 = 16).  One buffer with the largest count; rows a kernel does
         # not fill stay zero, exactly as in svgp_project.
         Tf = int(lib.nsgp_svgp_colstats_tiles(M, n, batch, 4))
-        T64 = int(lib.nsgp_svgp_f64acc_tiles_for(M, n, batch)) if W64f is not None else Tf
+        use_i8 = i8_inputs is not None and W64f is not None
+        T64 = (int(lib.nsgp_i8_tiles(M)) if use_i8 else int(lib.nsgp_svgp_f64acc_tiles_for(M, n, batch))) if W64f is not None else Tf
         T1 = T64 if W64f is not None else Tf                       # tile rows product 1 writes
         Tp = max(T1, T)
-        A = torch.empty_like(Kzx)
+        A = torch.empty((batch, M, n), dtype=ref.dtype, device=ref.device)
         part = (torch.zeros if (T1 != Tp or T != Tp) else torch.empty)((3, batch, max(Tp, 1), n), dtype=ref.dtype,
                                                                        device=ref.device)
         W = _c(W)
-        if W64f is not None:
+        if use_i8:
+            kZ, kx, kls, kos = i8_inputs
+            _project_a_i8(_c(W64f), _c(kZ), _c(kx), _c(kls), _c(kos.reshape(-1)), m, A, part[0], part[1], Tp, False, 4, flops)
+        elif W64f is not None:
             _timed(lambda: _lib.call('nsgp_svgp_tri_gemm_colstats_f64acc', _p(_c(W64f)), _p(Kzx), _p(m), batch, M, n, _p(A),
                                      _p(part[0]), _p(part[1]), Tp, st), flops, 'f64acc')
         elif Tp == Tf:

@@ -185,25 +185,37 @@ class SVGPLayerFn(torch.autograd.Function):
         # with the float64-accumulating product, whole tiles); the backward builds it once for Wbar = tril(Abar Kzx^T)
         fuse = fp == 'f32' and settings.fuse_kzx.on() and W64f is not None and \
             ops.svgp_kzx_fusable(W64f, Z, x, x.shape[-2])
-        # settings.hidden_kzx_f64: a layer that feeds the next one builds Kzx in float64 (inputs cast with one multi-tensor
-        # copy) for the float64-accumulating projection; its float32 Kzx is only needed by the backward, which builds it
+        # Which arithmetic for A = W Kzx (float32 layers with the float64 W of the whitening chain):
+        #  * a layer that feeds the next one (kzx_f64) and sees at most 8192 points -- the first hidden layer of a deep GP --
+        #    runs entirely in float64 accuracy (settings.hidden_kzx_f64 / hidden_var_f64: Kzx built in float64, both projections
+        #    on the float64-accumulating kernel, float64 partials): its mean AND its variance, whose cancellation needs A to
+        #    ~1e-9, reach the next layer; cheap at that size;
+        #  * every other layer: the exact int8 digit-plane product (settings.whiten_matmul_i8), with five Kzx planes / 19 plane
+        #    products when it feeds the next layer (A to float32 rounding) and four / 14 otherwise (1e-6 of max|A|);
+        #  * int8 off: the float64-accumulating product on the float32 Kzx (round 2), float64 Kzx for layers that feed the next.
         Kzx64 = Lq64 = None
-        if kzx_f64 and fp == 'f32' and W64f is not None and not fuse:
-            hv = settings.hidden_var_f64.value()
-            var64 = (x.shape[-2] <= 8192) if hv == 'auto' else bool(hv)
+        can64 = kzx_f64 and fp == 'f32' and W64f is not None and not fuse
+        hv = settings.hidden_var_f64.value()
+        var64 = can64 and ((x.shape[-2] <= 8192) if hv == 'auto' else bool(hv))
+        use_i8 = (fp in ('f32', 'bf16') and not fuse and not var64 and W64f is not None and settings.whiten_matmul_i8.on()
+                  and Z.shape[-1] <= 4 and Z.shape[-2] <= 4096)
+        if can64 and not use_i8:
             src = [x.detach(), Z.detach(), ls.detach(), os_.detach()] + ([Lq.detach()] if var64 else [])
             dst = [torch.empty(t.shape, dtype=torch.float64, device=t.device) for t in src]
             torch._foreach_copy_(dst, src)
             Kzx64 = ops.rbf_build(dst[1], dst[0], dst[2], dst[3])
             Lq64 = dst[4] if var64 else None  # C = Lq^T A accumulates in float64 too (the variance's cancellation)
-        Kzx = None if (fuse or Kzx64 is not None) else ops.rbf_build(Z, x, ls, os_)                     # (b,M,n)
+        Kzx = None if (fuse or Kzx64 is not None or use_i8) else ops.rbf_build(Z, x, ls, os_)           # (b,M,n)
         if x.dtype == torch.float32 and fp in ('bf16', 'bf16_all') and Z.shape[-2] % 8 == 0:
             # BASELINE configs[4]'s "bf16 forward": C = Lq^T A on the bf16 matrix cores; 'bf16_all' also A = W Kzx
             A, C, mean, var = ops.svgp_project_bf16(W, Kzx, Lq, m, os_, base_add=VAR_JITTER, affine=affine, W64f=W64f,
-                                                    kernel_inputs=(Z, x, ls, os_) if fp == 'bf16_all' else None)
+                                                    kernel_inputs=(Z, x, ls, os_) if fp == 'bf16_all' else None,
+                                                    i8_inputs=(Z, x, ls, os_) if (use_i8 and fp == 'bf16') else None)
         else:
             A, C, mean, var = ops.svgp_project(W, Kzx, Lq, m, os_, base_add=VAR_JITTER, affine=affine, W64f=W64f,
-                                               kernel_inputs=(Z, x, ls, os_) if fuse else None, Kzx64=Kzx64, Lq64=Lq64)      # 2 GEMMs
+                                               kernel_inputs=(Z, x, ls, os_) if fuse else None, Kzx64=Kzx64, Lq64=Lq64,
+                                               i8_inputs=(Z, x, ls, os_) if use_i8 else None,
+                                               i8_planes=5 if kzx_f64 else 4)      # 2 GEMMs
         ctx.save_for_backward(x, Z, ls, os_, m, Lq, W, Kzx, A, C, mean_w, mean_c)
         ctx.w_dtype = W64.dtype
         return mean, var

@@ -264,7 +264,7 @@ def test_layer_with_generated_kzx_matches_the_materialised_layer():
     for fuse in (False, True):
         for t in (x, Z, ls, os_, m, Lq):
             t.grad = None
-        with settings.fuse_kzx(fuse):
+        with settings.fuse_kzx(fuse), settings.whiten_matmul_i8(False):      # (both variants on the float64-accumulating product)
             mean, var, _ = svgp_marginal(x, Z, ls, os_, m, Lq)
             ((mean * gm).sum() + (var * gv).sum()).backward()
         outs.append([mean.detach().clone(), var.detach().clone()] + [t.grad.clone() for t in (x, Z, ls, os_, m, Lq)])

@@ -82,11 +82,12 @@ def run(args):
         ms64, fl64, n64 = timer.summary(torch.float64)
         msacc, flacc, nacc = timer.summary('f64acc')
         msbf, flbf, nbf = timer.summary('bf16')
+        msi8, fli8, ni8 = timer.summary('i8')
         ops.set_gemm_timer(None)
     return {
         'workload': f'3-layer DSVI DeepGP (tied 3->3 hidden x2 + last 3->1), M={args.M}, S={S}, minibatch {B}, '
                     f'synthetic N={N} 3-D grid; fwd+ELBO+bwd+Adam, float32 with float64 Kzz Cholesky; forward '
-                    f'projections: {args.forward}' + ('' if args.no_f64acc else ' (A accumulated in float64)'),
+                    f'projections: {args.forward}' + ('' if args.no_f64acc else ' (A = W Kzx as an exact int8 digit-plane product)'),
         'forward': args.forward, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(el / args.steps * 1e3, 2), 'steps_per_sec': round(args.steps / el, 2),
         'loss_first': round(float(losses[0]), 4), 'loss_last': round(float(losses[-1]), 4),
@@ -95,6 +96,8 @@ def run(args):
         'f32_gemm_launches': n32, 'f64_gemm_ms_per_step': round(ms64, 2), 'f64_gemm_launches': n64,
         'f64acc_gemm_ms_per_step': round(msacc, 2), 'f64acc_gemm_launches': nacc,
         'f64acc_gemm_TFLOPs': round(flacc / (msacc * 1e-3) / 1e12, 1) if nacc else None,
+        'i8_gemm_ms_per_step': round(msi8, 2), 'i8_gemm_launches': ni8,
+        'i8_gemm_TFLOPs_f64eq': round(fli8 / (msi8 * 1e-3) / 1e12, 1) if ni8 else None,
         'bf16_gemm_ms_per_step': round(msbf, 2), 'bf16_gemm_launches': nbf,
         'bf16_gemm_TFLOPs': round(flbf / (msbf * 1e-3) / 1e12, 1) if nbf else None,
         'hbm_peak_allocated_GB': round(torch.cuda.max_memory_allocated() / 1e9, 2)}
