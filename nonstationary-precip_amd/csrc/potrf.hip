@@ -31,6 +31,19 @@ extern "C" int nsgp_gemm_f64(int64_t, int64_t, int64_t, double, const double*, i
 
 namespace {
 
+#ifdef NSGP_POTRF_STAMPS
+// Diagnostic build only (tools/probes/potrf_stamps.py): workgroup 0 of matrix 0 records shader-clock stamps at the phase
+// boundaries of panel_body2, one 16-word record per panel launch.  Never in the shipped library.
+__device__ unsigned long long* nsgp_pstamp_buf = nullptr;
+__device__ unsigned long long nsgp_pstamp_cap = 0;
+#define NSGP_PSTAMP(i) do { if (pst_on) pst[i] = __builtin_amdgcn_s_memtime(); } while (0)
+// arrival of every wave at the barrier that ends a phase (record 16 + 8 w + i of the panel's 64 words)
+#define NSGP_WSTAMP(i) do { if (wst_on) wst[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define NSGP_PSTAMP(i) do { } while (0)
+#define NSGP_WSTAMP(i) do { } while (0)
+#endif
+
 constexpr int NB = 64;          // panel width
 constexpr int LDD = NB + 1;     // LDS leading dimension (odd: conflict-free column walks)
 
@@ -150,6 +163,10 @@ template <typename T, int C0> __device__ __forceinline__ int factor_subpanel(T* 
     for (int j = 0; j < SB; ++j) a[j] = S[lane * LDD + C0 + j];
     int bad = 0;
 #if NSGP_POTRF_LDSCOL
+    // (Tried in round 3 and dropped: FOUR pivots at a time -- the pivot rows publish the 4 x 4 diagonal block through LDS, every
+    // lane factors it redundantly in registers, solves its own row against it and takes the rank-4 update's multipliers from
+    // LDS as broadcast 128-bit reads.  Fewer instructions, but two LDS round trips and a 4-deep rsqrt chain per block: 1630
+    // cycles per four pivots against 940 here, tools/probes/potrf_stamps.py -- profiles/r03/potrf_stamps_blk4_experiment.log.)
     // The wave is bound by instruction issue, and 2/5 of its instructions were v_readlane pairs (one pair per rank-1 update
     // a[j] -= l_k[row] * l_k[C0 + j], the multiplier broadcast from lane C0 + j through an SGPR pair -- plus v_writelane spills
     // of those SGPRs).  Here only the update the NEXT pivot waits for (j = k + 1) takes that route; the pivot column's
@@ -213,21 +230,31 @@ template <typename T, int C0> __device__ __forceinline__ int factor_subpanel(T* 
 }
 
 // Inverse of the 16x16 diagonal sub-block B0 of the factored block: lane c < 16 builds column c by forward
-// substitution (L rows are broadcast reads from LDS, reciprocal pivots from rd).
+// substitution (L entries are broadcast reads from LDS, reciprocal pivots from rd).  All 136 reads are issued first
+// (independent, pipelined) and the substitution runs column by column -- x_k = acc_k / L_kk, then acc_i -= L_ik x_k for
+// every i > k, independent FMAs -- instead of row by row with a dependent FMA chain behind each LDS read: 3700 -> 1400 cycles
+// (float32; tools/probes/potrf_stamps.py), which took this off the critical path of the panel phases.  Same operations in the
+// same order per element as the row-by-row form: bit-identical results.
 template <typename T> __device__ __forceinline__ void invert_subblock(const T* S, const T* rd, T* Dinv, int B0,
                                                                       int lane) {
     if (lane >= SB) return;
     const T* Lw = S + (B0 * SB) * LDD + B0 * SB;
-    T x[SB];
+    T Lr[SB * (SB - 1) / 2], rv[SB], acc[SB];
 #pragma unroll
-    for (int i = 0; i < SB; ++i) {
-        T acc = lane == i ? T(1) : T(0);
+    for (int i = 1; i < SB; ++i)
 #pragma unroll
-        for (int k = 0; k < i; ++k) acc -= Lw[i * LDD + k] * x[k];
-        x[i] = i < lane ? T(0) : acc * rd[B0 * SB + i];
+        for (int k = 0; k < i; ++k) Lr[i * (i - 1) / 2 + k] = Lw[i * LDD + k];
+#pragma unroll
+    for (int i = 0; i < SB; ++i) { rv[i] = rd[B0 * SB + i]; acc[i] = lane == i ? T(1) : T(0); }
+#pragma unroll
+    for (int k = 0; k < SB; ++k) {
+        const T xk = k < lane ? T(0) : acc[k] * rv[k];
+        acc[k] = xk;
+#pragma unroll
+        for (int i = k + 1; i < SB; ++i) acc[i] -= Lr[i * (i - 1) / 2 + k] * xk;
     }
 #pragma unroll
-    for (int i = 0; i < SB; ++i) Dinv[(B0 * SB + i) * LDI + lane] = x[i];
+    for (int i = 0; i < SB; ++i) Dinv[(B0 * SB + i) * LDI + lane] = acc[i];
 }
 
 // FULL 64-wide panel.  grid.x = nslab workgroups of 4 waves, each factors the
@@ -438,32 +465,139 @@ __device__ __forceinline__ void rank64_tile(T* Ct, const T* Ar, const T* Br, int
     for (int r = 0; r < 4; ++r) Ct[MM::crow(r, lane) * LDD + fm] = acc[r];
 }
 
-// One column block CB of the blocked substitution  X L11^T = A21  for the 16-row strip Xw of the slab, by ONE wave:
-// X_cb = (A_cb - sum_{kb < cb} X_kb L[cb][kb]^T) Dinv_cb^T
-template <typename T, int CB>
-__device__ __forceinline__ void slab_subst_step(T* Xw, const T* S, const T* Dinv, int lane) {
+// NT such tiles, tile t at Ct + t * cstride with A rows at Ar + t * astride and B rows at Br + t * bstride (a stride of 0 shares
+// the operand; the repeated reads of a shared operand are to the same LDS words).  A tile is a chain of 16 DEPENDENT
+// MFMAs (one accumulator): alone it runs at the MFMA's latency, 1150 cycles (float32) for 512 cycles of matrix-core work, and
+// these tiles were the longest item of every panel phase (tools/probes/potrf_stamps.py).  Here the NT chains advance together,
+// so their MFMAs overlap; each tile's own arithmetic and its order are those of rank64_tile (bit-identical).
+template <typename T, int NT>
+__device__ __forceinline__ void rank64_tiles(T* Ct, int cstride, const T* Ar, int astride, const T* Br, int bstride, int lane) {
     typedef Mma16<T> MM;
     const int fm = lane & 15, fk = lane >> 4;
-    typename MM::acc_t acc;
+    // Every operand is requested before the first MFMA (left to itself the compiler fetches two k-steps at a time and waits
+    // for them: an exposed LDS latency per 8 MFMAs, 4300 cycles for 2048 of matrix-core work), and the sign lives in the
+    // accumulator -- (-C) + A B^T, negated back on the way out -- instead of a v_xor per A element: exact either way.
+    typename MM::acc_t acc[NT];
+    T av[NT][NB / 4], bv[NT][NB / 4];
+    // four groups of four k-steps: group g + 1 is requested before group g's MFMAs are issued (the scheduling barriers keep
+    // the compiler from sinking the reads back to their uses), so LDS latency hides behind 4 NT MFMAs
+    auto fetch = [&](int g) __attribute__((always_inline)) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = Xw[MM::crow(r, lane) * LDD + CB * SB + fm];
+        for (int kk = 4 * g; kk < 4 * g + 4; ++kk) {
 #pragma unroll
-    for (int kb = 0; kb < CB; ++kb)
+            for (int t = 0; t < NT; ++t) {
+                av[t][kk] = Ar[t * astride + fm * LDD + 4 * kk + fk];
+                bv[t][kk] = Br[t * bstride + fm * LDD + 4 * kk + fk];
+            }
+        }
+    };
+    fetch(0);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-            acc = MM::mma(-Xw[fm * LDD + kb * SB + 4 * kk + fk], S[(CB * SB + fm) * LDD + kb * SB + 4 * kk + fk], acc);
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = -Ct[t * cstride + MM::crow(r, lane) * LDD + fm];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (g < 3) fetch(g + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 4 * g; kk < 4 * g + 4; ++kk)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = MM::mma(av[t][kk], bv[t][kk], acc[t]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ct[t * cstride + MM::crow(r, lane) * LDD + fm] = -acc[t][r];
+}
+
+// ONE tile with its K range cut into four accumulator chains (k = 4 kk + fk, chain kk mod 4), summed at the end: for the tile
+// every wave updates alone before the first sub-panel can start (U0).  Not the summation order of rank64_tile -- the panel and
+// the inverse's row-block workgroups both take this route for the same data, so they still agree bit for bit.
+template <typename T>
+__device__ __forceinline__ void rank64_tile_split(T* Ct, const T* Ar, const T* Br, int lane) {
+    typedef Mma16<T> MM;
+    const int fm = lane & 15, fk = lane >> 4;
+    typename MM::acc_t acc[4];
+    T av[NB / 4], bv[NB / 4];
+#pragma unroll
+    for (int kk = 0; kk < NB / 4; ++kk) { av[kk] = Ar[fm * LDD + 4 * kk + fk]; bv[kk] = Br[fm * LDD + 4 * kk + fk]; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        acc[0][r] = -Ct[MM::crow(r, lane) * LDD + fm];
+        acc[1][r] = T(0); acc[2][r] = T(0); acc[3][r] = T(0);
+    }
+    if constexpr (sizeof(T) == 4) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < NB / 4; ++kk) acc[kk & 3] = MM::mma(av[kk], bv[kk], acc[kk & 3]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ct[MM::crow(r, lane) * LDD + fm] = -((acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]));
+}
+
+// One column block CB of the blocked substitution  X L11^T = A21  for NS 16-row strips of the slab (strip s at Xw + s * sstride),
+// by ONE wave:  X_cb = (A_cb - sum_{kb < cb} X_kb L[cb][kb]^T) Dinv_cb^T.  The strips' accumulator chains advance together
+// (see rank64_tiles); per strip the arithmetic and its order do not depend on NS.
+template <typename T, int CB, int NS = 1>
+__device__ __forceinline__ void slab_subst_step(T* Xw, const T* S, const T* Dinv, int lane, int sstride = 0) {
+    typedef Mma16<T> MM;
+    const int fm = lane & 15, fk = lane >> 4;
+    typename MM::acc_t acc[NS];
+    constexpr int KS = CB * 4 > 0 ? CB * 4 : 1;
+    T lv[KS], xv[NS][KS], dv[4];
+#pragma unroll
+    for (int q = 0; q < CB * 4; ++q) lv[q] = S[(CB * SB + fm) * LDD + 4 * q + fk];       // k = 16 kb + 4 kk + fk = 4 q + fk
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int q = 0; q < CB * 4; ++q) xv[s][q] = Xw[s * sstride + fm * LDD + 4 * q + fk];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) dv[kk] = Dinv[(CB * SB + fm) * LDI + 4 * kk + fk];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[s][r] = -Xw[s * sstride + MM::crow(r, lane) * LDD + CB * SB + fm];
+    if constexpr (sizeof(T) == 4) __builtin_amdgcn_sched_barrier(0);   // float64: MFMA-bound, the compiler's own interleaving is better
+#pragma unroll
+    for (int q = 0; q < CB * 4; ++q)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[s] = MM::mma(xv[s][q], lv[q], acc[s]);
     wave_sync();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Xw[MM::crow(r, lane) * LDD + CB * SB + fm] = acc[r];
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Xw[s * sstride + MM::crow(r, lane) * LDD + CB * SB + fm] = -acc[s][r];
     wave_sync();
-    typename MM::acc_t y = {T(0), T(0), T(0), T(0)};
+    typename MM::acc_t y[NS];
+    T xr[NS][4];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        y[s] = typename MM::acc_t{T(0), T(0), T(0), T(0)};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) xr[s][kk] = Xw[s * sstride + fm * LDD + CB * SB + 4 * kk + fk];
+    }
+    if constexpr (sizeof(T) == 4) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
-        y = MM::mma(Xw[fm * LDD + CB * SB + 4 * kk + fk], Dinv[(CB * SB + fm) * LDI + 4 * kk + fk], y);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) y[s] = MM::mma(xr[s][kk], dv[kk], y[s]);
     wave_sync();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Xw[MM::crow(r, lane) * LDD + CB * SB + fm] = y[r];
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Xw[s * sstride + MM::crow(r, lane) * LDD + CB * SB + fm] = y[s][r];
     wave_sync();
+}
+
+// F0 work of waves 1..3 on the diagonal block: S -= P P^T on the tiles ON OR BELOW the diagonal of column tiles 1..3 (the
+// factorisation never reads above it; six of the twelve tiles used to be updated for nothing) -- wave 1: (1..3, 1), wave 2:
+// (2..3, 2), wave 3: (3, 3).  panel_body2 and prow_body both come through here: same arithmetic on the same data.
+template <typename T>
+__device__ __forceinline__ void diag_prev_update(T* S, const T* Ps, int w, int lane) {
+    constexpr int RS = SB * LDD;
+    if (w == 1) rank64_tiles<T, 3>(S + RS + SB, RS, Ps + RS, RS, Ps + RS, 0, lane);
+    else if (w == 2) rank64_tiles<T, 2>(S + 2 * RS + 2 * SB, RS, Ps + 2 * RS, RS, Ps + 2 * RS, 0, lane);
+    else if (w == 3) rank64_tile_split<T>(S + 3 * RS + 3 * SB, Ps + 3 * RS, Ps + 3 * RS, lane);
 }
 
 // Panel with the idle waves put to work.  While wave 0 factors a 16-column sub-panel in registers (2.7 us, 4 times per
@@ -494,6 +628,12 @@ __device__ __forceinline__ void panel_body2(unsigned char* panel_smem, T* __rest
     const int64_t r0 = j0 + NB + blk * NB;
     const int rows = r0 >= n ? 0 : (int)((n - r0) < NB ? (n - r0) : NB);
     const int fm = lane & 15, fk = lane >> 4;
+#ifdef NSGP_POTRF_STAMPS
+    unsigned long long pst[16] = {}, wst[8] = {};
+    const bool pst_on = tid == 0 && blk == 0 && b == 0;
+    const bool wst_on = lane == 0 && blk == 0 && b == 0;
+#endif
+    NSGP_PSTAMP(0);
     {
         T dr[SB], xr[SB], pr[SB], qr[SB];                // loads first, LDS stores after (one exposed latency)
 #pragma unroll
@@ -528,20 +668,22 @@ __device__ __forceinline__ void panel_body2(unsigned char* panel_smem, T* __rest
         }
     }
     __syncthreads();
+    NSGP_PSTAMP(1);
     if (pre) {                                           // U0: columns 0..15 of S -= P P^T (what sub-panel 0 needs)
-        rank64_tile<T>(S + (w * SB) * LDD, Ps + (w * SB) * LDD, Ps, lane);
+        rank64_tile_split<T>(S + (w * SB) * LDD, Ps + (w * SB) * LDD, Ps, lane);
         __syncthreads();
     }
+    NSGP_PSTAMP(2);
     const bool slab = rows > 0;
     int bad = 0;
     // ---- F0 ----
-    if (w == 0) { const int bd = factor_subpanel<T, 0>(S, rd, Qs + NB * LDD, lane); if (bad == 0) bad = bd; }
+    if (w == 0) { const int bd = factor_subpanel<T, 0>(S, rd, Qs + NB * LDD, lane); if (bad == 0) bad = bd; NSGP_PSTAMP(3); }
     else if (pre) {
-        for (int q = w - 1; q < 12; q += 3) {            // (row block, column tile 1..3) of S -= P P^T
-            const int rb = q / 3, t = 1 + q % 3;
-            rank64_tile<T>(S + (rb * SB) * LDD + t * SB, Ps + (rb * SB) * LDD, Ps + (t * SB) * LDD, lane);
-        }
+        diag_prev_update<T>(S, Ps, w, lane);
+        // ... and, behind the short lists, slab tiles that wait for nothing: X -= Q P^T, (strip, column tile) = (0, 2), (1, 2)
+        if (w == 3 && slab) rank64_tiles<T, 2>(Xs + 2 * SB, SB * LDD, Qs, SB * LDD, Ps + (2 * SB) * LDD, 0, lane);
     }
+    NSGP_WSTAMP(0);
     __syncthreads();
 #define NSGP_TRAIL(C0)                                                                                \
     {                                                                                                 \
@@ -562,57 +704,62 @@ __device__ __forceinline__ void panel_body2(unsigned char* panel_smem, T* __rest
             _Pragma("unroll") for (int r = 0; r < 4; ++r)                                             \
                 S[(ti * SB + MM::crow(r, lane)) * LDD + tj * SB + fm] = acc[r];                       \
         }                                                                                             \
+        NSGP_WSTAMP(1 + 2 * B0);                                                                      \
         if (NT > 0) __syncthreads();                                                                  \
     }
+    NSGP_PSTAMP(4);
     NSGP_TRAIL(0)
+    NSGP_PSTAMP(5);
     // ---- F1 ----
-    if (w == 0) { const int bd = factor_subpanel<T, 16>(S, rd, Qs + NB * LDD, lane); if (bad == 0) bad = bd; }
+    if (w == 0) { const int bd = factor_subpanel<T, 16>(S, rd, Qs + NB * LDD, lane); if (bad == 0) bad = bd; NSGP_PSTAMP(6); }
     else {
-        // X -= Q P^T, 16 (strip, column tile) tasks over F1 and F2: column tiles 0 and 1 now (waves 2, 3: the substitution
-        // needs them first), tile 2 by wave 1 behind its inversions, tile 3 in F2
-        auto xtile = [&](int rb, int t) __attribute__((always_inline)) {
-            rank64_tile<T>(Xs + (rb * SB) * LDD + t * SB, Qs + (rb * SB) * LDD, Ps + (t * SB) * LDD, lane);
-        };
-        if (w == 1) {
+        // X -= Q P^T, 16 (strip, column tile) tasks over F0 .. F2, at most three to a wave and phase (float64: a tile is 1024
+        // cycles of matrix-core time, a sub-panel factorisation 4900): column tiles 0 and 1 now (the substitution needs them
+        // first), tile 2 in F0 / F2 (wave 3 / wave 1), tile 3 in F2
+        if (w == 1) {                                    // strip 3 of column tiles 0 and 1 (shares Q's rows)
             invert_subblock<T>(S, rd, Dinv, 0, lane);
-            if (pre && slab) { xtile(0, 2); xtile(1, 2); }
-        } else if (pre && slab) {
-            for (int rb = 0; rb < 4; ++rb) xtile(rb, w - 2);
+            if (pre && slab) rank64_tiles<T, 2>(Xs + (3 * SB) * LDD, SB, Qs + (3 * SB) * LDD, 0, Ps, SB * LDD, lane);
+        } else if (pre && slab) {                        // strips 0..2 of column tile w - 2
+            rank64_tiles<T, 3>(Xs + (w - 2) * SB, SB * LDD, Qs, SB * LDD, Ps + ((w - 2) * SB) * LDD, 0, lane);
         }
     }
+    NSGP_WSTAMP(2);
     __syncthreads();
+    NSGP_PSTAMP(7);
     NSGP_TRAIL(16)
+    NSGP_PSTAMP(8);
     // ---- F2 ----
-    if (w == 0) { const int bd = factor_subpanel<T, 32>(S, rd, Qs + NB * LDD, lane); if (bad == 0) bad = bd; }
+    if (w == 0) { const int bd = factor_subpanel<T, 32>(S, rd, Qs + NB * LDD, lane); if (bad == 0) bad = bd; NSGP_PSTAMP(9); }
     else {
-        auto xtile = [&](int rb, int t) __attribute__((always_inline)) {
-            rank64_tile<T>(Xs + (rb * SB) * LDD + t * SB, Qs + (rb * SB) * LDD, Ps + (t * SB) * LDD, lane);
-        };
         if (w == 1) {
             invert_subblock<T>(S, rd, Dinv, 1, lane);
-            if (pre && slab) { xtile(2, 2); xtile(3, 2); }
+            if (pre && slab) rank64_tiles<T, 2>(Xs + (2 * SB) * LDD + 2 * SB, SB * LDD, Qs + (2 * SB) * LDD, SB * LDD,
+                                                Ps + (2 * SB) * LDD, 0, lane);
         } else if (slab) {                               // waves 2, 3: strips {0, 2} and {1, 3}
-            if (pre) { xtile(w - 2, 3); xtile(w, 3); }
-            slab_subst_step<T, 0>(Xs + ((w - 2) * SB) * LDD, S, Dinv, lane);
-            slab_subst_step<T, 0>(Xs + ((w) * SB) * LDD, S, Dinv, lane);
+            if (pre) rank64_tiles<T, 2>(Xs + ((w - 2) * SB) * LDD + 3 * SB, 2 * SB * LDD, Qs + ((w - 2) * SB) * LDD, 2 * SB * LDD,
+                                        Ps + (3 * SB) * LDD, 0, lane);
+            slab_subst_step<T, 0, 2>(Xs + ((w - 2) * SB) * LDD, S, Dinv, lane, 2 * SB * LDD);
         }
     }
+    NSGP_WSTAMP(4);
     __syncthreads();
+    NSGP_PSTAMP(10);
     NSGP_TRAIL(32)
+    NSGP_PSTAMP(11);
     // ---- F3 ----
-    if (w == 0) { const int bd = factor_subpanel<T, 48>(S, rd, Qs + NB * LDD, lane); if (bad == 0) bad = bd; }
+    if (w == 0) { const int bd = factor_subpanel<T, 48>(S, rd, Qs + NB * LDD, lane); if (bad == 0) bad = bd; NSGP_PSTAMP(12); }
     else if (w == 1) invert_subblock<T>(S, rd, Dinv, 2, lane);
     else if (slab) {
-        slab_subst_step<T, 1>(Xs + ((w - 2) * SB) * LDD, S, Dinv, lane);
-        slab_subst_step<T, 1>(Xs + ((w) * SB) * LDD, S, Dinv, lane);
+        slab_subst_step<T, 1, 2>(Xs + ((w - 2) * SB) * LDD, S, Dinv, lane, 2 * SB * LDD);
     }
+    NSGP_WSTAMP(6);
     __syncthreads();
+    NSGP_PSTAMP(13);
 #undef NSGP_TRAIL
     // ---- after the last sub-panel ----
     if (w == 1) invert_subblock<T>(S, rd, Dinv, 3, lane);
     else if (w >= 2 && slab) {
-        slab_subst_step<T, 2>(Xs + ((w - 2) * SB) * LDD, S, Dinv, lane);
-        slab_subst_step<T, 2>(Xs + ((w) * SB) * LDD, S, Dinv, lane);
+        slab_subst_step<T, 2, 2>(Xs + ((w - 2) * SB) * LDD, S, Dinv, lane, 2 * SB * LDD);
     }
     if (blk == 0) {
         T* dst = wsL + (b * npanels + pj) * NB * NB;
@@ -624,13 +771,24 @@ __device__ __forceinline__ void panel_body2(unsigned char* panel_smem, T* __rest
             else if (bad && info[b] == 0) info[b] = (int32_t)(j0 + bad);
         }
     }
+    NSGP_WSTAMP(7);
     __syncthreads();
-    if (!slab) return;                                   // workgroup-uniform
-    T* Xw = Xs + (w * SB) * LDD;                         // last column block: every wave its own strip
-    slab_subst_step<T, 3>(Xw, S, Dinv, lane);
+    NSGP_PSTAMP(14);
+    if (slab) {                                          // workgroup-uniform
+        T* Xw = Xs + (w * SB) * LDD;                     // last column block: every wave its own strip
+        slab_subst_step<T, 3>(Xw, S, Dinv, lane);
 #pragma unroll
-    for (int i = 0; i < SB; ++i)
-        if (w * SB + i < rows) Ab[(r0 + w * SB + i) * lda + j0 + lane] = Xw[i * LDD + lane];
+        for (int i = 0; i < SB; ++i)
+            if (w * SB + i < rows) Ab[(r0 + w * SB + i) * lda + j0 + lane] = Xw[i * LDD + lane];
+    }
+#ifdef NSGP_POTRF_STAMPS
+    if (pst_on && nsgp_pstamp_buf && (unsigned long long)pj < nsgp_pstamp_cap) {
+        pst[15] = __builtin_amdgcn_s_memtime();
+        for (int i = 0; i < 16; ++i) nsgp_pstamp_buf[pj * 64 + i] = pst[i];
+    }
+    if (wst_on && nsgp_pstamp_buf && (unsigned long long)pj < nsgp_pstamp_cap)
+        for (int i = 0; i < 8; ++i) nsgp_pstamp_buf[pj * 64 + 16 + 8 * w + i] = wst[i];
+#endif
 }
 
 // Rank-64 trailing update  C -= L21 L21^T  on the lower 64x64 tiles of a (rows x wcols) region, one tile per
@@ -756,31 +914,93 @@ __device__ __forceinline__ void rank64_tile_kn(T* Ct, const T* Ar, const T* Bk, 
     for (int r = 0; r < 4; ++r) Ct[MM::crow(r, lane) * LDD + fm] = acc[r];
 }
 
-// Row block RB of the blocked substitution  L11 Y = R  for the 16-COLUMN strip Rc of a 64 x 64 block, by ONE wave:
-// Y_rb = Dinv_rb (R_rb - sum_{kb < rb} L[rb][kb] Y_kb)      (Y overwrites R; Rc points at the strip's first column)
-template <typename T, int RB>
-__device__ __forceinline__ void prow_subst_step(T* Rc, const T* S, const T* Dinv, int lane) {
+// NT such tiles that share A: tile t at Ct + 16 t against B columns Bk + 16 t (accumulator chains interleaved, see rank64_tiles)
+template <typename T, int NT>
+__device__ __forceinline__ void rank64_tiles_kn(T* Ct, const T* Ar, const T* Bk, int lane) {
     typedef Mma16<T> MM;
     const int fm = lane & 15, fk = lane >> 4;
-    typename MM::acc_t acc;
+    typename MM::acc_t acc[NT];
+    T av[NB / 4], bv[NT][NB / 4];
+    auto fetch = [&](int g) __attribute__((always_inline)) {       // as rank64_tiles: one group of k-steps ahead
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = Rc[(RB * SB + MM::crow(r, lane)) * LDD + fm];
+        for (int kk = 4 * g; kk < 4 * g + 4; ++kk) {
+            av[kk] = Ar[fm * LDD + 4 * kk + fk];
 #pragma unroll
-    for (int kb = 0; kb < RB; ++kb)
+            for (int t = 0; t < NT; ++t) bv[t][kk] = Bk[t * SB + (4 * kk + fk) * LDD + fm];
+        }
+    };
+    fetch(0);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-            acc = MM::mma(-S[(RB * SB + fm) * LDD + kb * SB + 4 * kk + fk], Rc[(kb * SB + 4 * kk + fk) * LDD + fm], acc);
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = -Ct[t * SB + MM::crow(r, lane) * LDD + fm];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (g < 3) fetch(g + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 4 * g; kk < 4 * g + 4; ++kk)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = MM::mma(av[kk], bv[t][kk], acc[t]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ct[t * SB + MM::crow(r, lane) * LDD + fm] = -acc[t][r];
+}
+
+// Row block RB of the blocked substitution  L11 Y = R  for NS 16-COLUMN strips of a 64 x 64 block (strip s at Rc + s * cstride),
+// by ONE wave:  Y_rb = Dinv_rb (R_rb - sum_{kb < rb} L[rb][kb] Y_kb)      (Y overwrites R; Rc points at the first strip's first
+// column).  The strips' accumulator chains advance together; per strip the arithmetic and its order do not depend on NS.
+template <typename T, int RB, int NS = 1>
+__device__ __forceinline__ void prow_subst_step(T* Rc, const T* S, const T* Dinv, int lane, int cstride = 0) {
+    typedef Mma16<T> MM;
+    const int fm = lane & 15, fk = lane >> 4;
+    typename MM::acc_t acc[NS];
+    constexpr int KS = RB * 4 > 0 ? RB * 4 : 1;
+    T lv[KS], rv[NS][KS], dv[4];
+#pragma unroll
+    for (int q = 0; q < RB * 4; ++q) lv[q] = S[(RB * SB + fm) * LDD + 4 * q + fk];       // k = 16 kb + 4 kk + fk = 4 q + fk
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int q = 0; q < RB * 4; ++q) rv[s][q] = Rc[s * cstride + (4 * q + fk) * LDD + fm];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) dv[kk] = Dinv[(RB * SB + fm) * LDI + 4 * kk + fk];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[s][r] = -Rc[s * cstride + (RB * SB + MM::crow(r, lane)) * LDD + fm];
+    if constexpr (sizeof(T) == 4) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < RB * 4; ++q)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[s] = MM::mma(lv[q], rv[s][q], acc[s]);
     wave_sync();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Rc[(RB * SB + MM::crow(r, lane)) * LDD + fm] = acc[r];
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Rc[s * cstride + (RB * SB + MM::crow(r, lane)) * LDD + fm] = -acc[s][r];
     wave_sync();
-    typename MM::acc_t y = {T(0), T(0), T(0), T(0)};
+    typename MM::acc_t y[NS];
+    T rr[NS][4];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        y[s] = typename MM::acc_t{T(0), T(0), T(0), T(0)};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) rr[s][kk] = Rc[s * cstride + (RB * SB + 4 * kk + fk) * LDD + fm];
+    }
+    if constexpr (sizeof(T) == 4) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
-        y = MM::mma(Dinv[(RB * SB + fm) * LDI + 4 * kk + fk], Rc[(RB * SB + 4 * kk + fk) * LDD + fm], y);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) y[s] = MM::mma(dv[kk], rr[s][kk], y[s]);
     wave_sync();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Rc[(RB * SB + MM::crow(r, lane)) * LDD + fm] = y[r];
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Rc[s * cstride + (RB * SB + MM::crow(r, lane)) * LDD + fm] = y[s][r];
     wave_sync();
 }
 
@@ -851,16 +1071,13 @@ __device__ __forceinline__ void prow_body(unsigned char* panel_smem, const T* __
     }
     __syncthreads();
     if (pre) {                                           // U0: columns 0..15 of S -= P P^T
-        rank64_tile<T>(S + (w * SB) * LDD, Ps + (w * SB) * LDD, Ps, lane);
+        rank64_tile_split<T>(S + (w * SB) * LDD, Ps + (w * SB) * LDD, Ps, lane);
         __syncthreads();
     }
     // ---- F0 ----
     if (w == 0) (void)factor_subpanel<T, 0>(S, rd, Qs + NB * LDD, lane);
     else if (pre) {
-        for (int q = w - 1; q < 12; q += 3) {
-            const int rb = q / 3, t = 1 + q % 3;
-            rank64_tile<T>(S + (rb * SB) * LDD + t * SB, Ps + (rb * SB) * LDD, Ps + (t * SB) * LDD, lane);
-        }
+        diag_prev_update<T>(S, Ps, w, lane);
     }
     __syncthreads();
 #define NSGP_TRAIL(C0)                                                                                \
@@ -885,18 +1102,18 @@ __device__ __forceinline__ void prow_body(unsigned char* panel_smem, const T* __
         if (NT > 0) __syncthreads();                                                                  \
     }
     NSGP_TRAIL(0)
-    // R -= L[j][j-1] W[j-1][c]: tile (row block rb, column tile t)
-    auto rtile = [&](int rb, int t) __attribute__((always_inline)) {
-        rank64_tile_kn<T>(Rs + (rb * SB) * LDD + t * SB, Ps + (rb * SB) * LDD, Qs + t * SB, lane);
+    // R -= L[j][j-1] W[j-1][c]: tiles (row block rb, column tiles t, t + 1, ...) share the rows of L
+    auto rtiles2 = [&](int rb, int t) __attribute__((always_inline)) {
+        rank64_tiles_kn<T, 2>(Rs + (rb * SB) * LDD + t * SB, Ps + (rb * SB) * LDD, Qs + t * SB, lane);
     };
     // ---- F1 ----  (the substitution walks row blocks 0, 1, 2, 3 of EVERY column strip: all column tiles of row blocks 0
     // and 1 first)
     if (w == 0) (void)factor_subpanel<T, 16>(S, rd, Qs + NB * LDD, lane);
     else if (w == 1) {
         invert_subblock<T>(S, rd, Dinv, 0, lane);
-        if (upd) { rtile(2, 0); rtile(2, 1); }
+        if (upd) rtiles2(2, 0);
     } else if (upd) {
-        for (int t = 0; t < 4; ++t) rtile(w - 2, t);
+        rank64_tiles_kn<T, 4>(Rs + ((w - 2) * SB) * LDD, Ps + ((w - 2) * SB) * LDD, Qs, lane);
     }
     __syncthreads();
     NSGP_TRAIL(16)
@@ -904,11 +1121,10 @@ __device__ __forceinline__ void prow_body(unsigned char* panel_smem, const T* __
     if (w == 0) (void)factor_subpanel<T, 32>(S, rd, Qs + NB * LDD, lane);
     else if (w == 1) {
         invert_subblock<T>(S, rd, Dinv, 1, lane);
-        if (upd) { rtile(2, 2); rtile(2, 3); }
+        if (upd) rtiles2(2, 2);
     } else {
-        if (upd) { rtile(3, 2 * (w - 2)); rtile(3, 2 * (w - 2) + 1); }
-        prow_subst_step<T, 0>(Rs + (w - 2) * SB, S, Dinv, lane);          // column strips {0, 2} and {1, 3}
-        prow_subst_step<T, 0>(Rs + (w) * SB, S, Dinv, lane);
+        if (upd) rtiles2(3, 2 * (w - 2));
+        prow_subst_step<T, 0, 2>(Rs + (w - 2) * SB, S, Dinv, lane, 2 * SB);          // column strips {0, 2} and {1, 3}
     }
     __syncthreads();
     NSGP_TRAIL(32)
@@ -916,15 +1132,13 @@ __device__ __forceinline__ void prow_body(unsigned char* panel_smem, const T* __
     if (w == 0) (void)factor_subpanel<T, 48>(S, rd, Qs + NB * LDD, lane);
     else if (w == 1) invert_subblock<T>(S, rd, Dinv, 2, lane);
     else {
-        prow_subst_step<T, 1>(Rs + (w - 2) * SB, S, Dinv, lane);
-        prow_subst_step<T, 1>(Rs + (w) * SB, S, Dinv, lane);
+        prow_subst_step<T, 1, 2>(Rs + (w - 2) * SB, S, Dinv, lane, 2 * SB);
     }
     __syncthreads();
 #undef NSGP_TRAIL
     if (w == 1) invert_subblock<T>(S, rd, Dinv, 3, lane);
     else if (w >= 2) {
-        prow_subst_step<T, 2>(Rs + (w - 2) * SB, S, Dinv, lane);
-        prow_subst_step<T, 2>(Rs + (w) * SB, S, Dinv, lane);
+        prow_subst_step<T, 2, 2>(Rs + (w - 2) * SB, S, Dinv, lane, 2 * SB);
     }
     __syncthreads();
     prow_subst_step<T, 3>(Rs + w * SB, S, Dinv, lane);                    // last row block: every wave its column strip
@@ -1332,6 +1546,15 @@ int potrf_trtri_impl(T* A, int64_t n, int64_t lda, int64_t sA, int64_t batch, in
 }  // namespace
 
 extern "C" {
+#ifdef NSGP_POTRF_STAMPS
+int nsgp_debug_potrf_stamps(void* buf, uint64_t cap_records) {
+    unsigned long long* b = (unsigned long long*)buf;
+    unsigned long long c = cap_records;
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(nsgp_pstamp_buf), &b, sizeof(b));
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(nsgp_pstamp_cap), &c, sizeof(c));
+    return (int)e;
+}
+#endif
 
 size_t nsgp_potrf_workspace(int64_t n, int64_t batch, int elem_size) {
     if (n <= 0 || batch <= 0) return 0;

@@ -123,7 +123,24 @@ __global__ __launch_bounds__(256) void rowdot_affine_kernel(const T* __restrict_
         constexpr int V = 16 / sizeof(T);
         const bool vec = (n % V == 0) && ((uintptr_t)row % 16 == 0) && ((uintptr_t)gb % 16 == 0);
         if (vec) {
-            for (int64_t j = (int64_t)threadIdx.x * V; j < n; j += 256 * V) {
+            int64_t j = (int64_t)threadIdx.x * V;
+            if constexpr (sizeof(T) == 4) {
+                // four independent 16-byte loads of each operand in flight per lane (one per iteration left the row read at
+                // 2 TB/s: 85 us for the 1024 x 40960 A of the headline step's last layer)
+                T a1 = T(0), a2 = T(0), a3 = T(0);
+                for (; j + 3 * 256 * V < n; j += 4 * 256 * V) {
+                    const float4 p0 = *reinterpret_cast<const float4*>(row + j), q0 = *reinterpret_cast<const float4*>(gb + j);
+                    const float4 p1 = *reinterpret_cast<const float4*>(row + j + 256 * V), q1 = *reinterpret_cast<const float4*>(gb + j + 256 * V);
+                    const float4 p2 = *reinterpret_cast<const float4*>(row + j + 512 * V), q2 = *reinterpret_cast<const float4*>(gb + j + 512 * V);
+                    const float4 p3 = *reinterpret_cast<const float4*>(row + j + 768 * V), q3 = *reinterpret_cast<const float4*>(gb + j + 768 * V);
+                    acc += p0.x * q0.x + p0.y * q0.y + p0.z * q0.z + p0.w * q0.w;
+                    a1 += p1.x * q1.x + p1.y * q1.y + p1.z * q1.z + p1.w * q1.w;
+                    a2 += p2.x * q2.x + p2.y * q2.y + p2.z * q2.z + p2.w * q2.w;
+                    a3 += p3.x * q3.x + p3.y * q3.y + p3.z * q3.z + p3.w * q3.w;
+                }
+                acc = (acc + a1) + (a2 + a3);
+            }
+            for (; j < n; j += 256 * V) {
                 if constexpr (sizeof(T) == 4) {
                     const float4 a = *reinterpret_cast<const float4*>(row + j);
                     const float4 q = *reinterpret_cast<const float4*>(gb + j);

@@ -168,7 +168,7 @@ class hidden_var_f64(_value_context):
     True / False, or 'auto' (default): on where the layer sees at most 8192 points per output GP -- the first hidden layer
     of a deep GP (its inputs are the minibatch); deeper hidden layers see S x minibatch points, where the float64 product
     costs as much as the whole float32 layer (+12 % on a BASELINE configs[4] step)."""
-    _value = 'auto'
+    _global_value = 'auto'
 
 
 class check_mvn_cholesky(_feature_flag):

@@ -186,18 +186,21 @@ class SVGPLayerFn(torch.autograd.Function):
         fuse = fp == 'f32' and settings.fuse_kzx.on() and W64f is not None and \
             ops.svgp_kzx_fusable(W64f, Z, x, x.shape[-2])
         # Which arithmetic for A = W Kzx (float32 layers with the float64 W of the whitening chain):
-        #  * a layer that feeds the next one (kzx_f64) and sees at most 8192 points -- the first hidden layer of a deep GP --
-        #    runs entirely in float64 accuracy (settings.hidden_kzx_f64 / hidden_var_f64: Kzx built in float64, both projections
-        #    on the float64-accumulating kernel, float64 partials): its mean AND its variance, whose cancellation needs A to
-        #    ~1e-9, reach the next layer; cheap at that size;
-        #  * every other layer: the exact int8 digit-plane product (settings.whiten_matmul_i8), with five Kzx planes / 19 plane
-        #    products when it feeds the next layer (A to float32 rounding) and four / 14 otherwise (1e-6 of max|A|);
-        #  * int8 off: the float64-accumulating product on the float32 Kzx (round 2), float64 Kzx for layers that feed the next.
+        #  * the exact int8 digit-plane product (settings.whiten_matmul_i8; M <= 4096, D <= 4): four Kzx planes / 14 plane
+        #    products (1e-6 of max|A|), five / 19 for a layer that feeds the next one (kzx_f64: A to float32 rounding);
+        #  * int8 off: the float64-accumulating product on the float32 Kzx (round 2) -- on a float64 Kzx for a layer that
+        #    feeds the next one (settings.hidden_kzx_f64).
+        # And for C = Lq^T A: float32, except for a layer that feeds the next one and sees at most 8192 points -- the first
+        # hidden layer of a deep GP (settings.hidden_var_f64) -- where it accumulates in float64 with float64 column-statistic
+        # partials: the variance os + colsum(C^2 - A^2) cancels to << os once q(u) has trained and reaches the next layer's
+        # inputs through sqrt(var) eps.  Measured after 1000 Adam steps at the headline shape (max-norm, vs the float64
+        # oracle; tests/test_gpu_headline_precision.py): output mean 4.4e-6 with it, 5.2e-5 without (the reference's own
+        # float32 arithmetic: 4.5e-4); +0.12 ms on a 4.34 ms step.
         Kzx64 = Lq64 = None
         can64 = kzx_f64 and fp == 'f32' and W64f is not None and not fuse
         hv = settings.hidden_var_f64.value()
         var64 = can64 and ((x.shape[-2] <= 8192) if hv == 'auto' else bool(hv))
-        use_i8 = (fp in ('f32', 'bf16') and not fuse and not var64 and W64f is not None and settings.whiten_matmul_i8.on()
+        use_i8 = (fp in ('f32', 'bf16') and not fuse and W64f is not None and settings.whiten_matmul_i8.on()
                   and Z.shape[-1] <= 4 and Z.shape[-2] <= 4096)
         if can64 and not use_i8:
             src = [x.detach(), Z.detach(), ls.detach(), os_.detach()] + ([Lq.detach()] if var64 else [])
@@ -205,6 +208,8 @@ class SVGPLayerFn(torch.autograd.Function):
             torch._foreach_copy_(dst, src)
             Kzx64 = ops.rbf_build(dst[1], dst[0], dst[2], dst[3])
             Lq64 = dst[4] if var64 else None  # C = Lq^T A accumulates in float64 too (the variance's cancellation)
+        elif var64:
+            Lq64 = ops.cast(Lq.detach(), torch.float64)
         Kzx = None if (fuse or Kzx64 is not None or use_i8) else ops.rbf_build(Z, x, ls, os_)           # (b,M,n)
         if x.dtype == torch.float32 and fp in ('bf16', 'bf16_all') and Z.shape[-2] % 8 == 0:
             # BASELINE configs[4]'s "bf16 forward": C = Lq^T A on the bf16 matrix cores; 'bf16_all' also A = W Kzx

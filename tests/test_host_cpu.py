@@ -87,6 +87,12 @@ def test_settings_contexts_and_transform_cache_scope():
     from nsgp.gp.module import transform_cache
     import nsgp.gp as gp
     assert settings.num_likelihood_samples.value() == 10
+    # defaults the precision policy of nsgp/svgp.py reads (a missing default silently switched the float64 hidden path off)
+    assert settings.hidden_var_f64.value() == 'auto' and settings.hidden_kzx_f64.on() and settings.whiten_matmul_i8.on()
+    assert settings.forward_precision.value() == 'f32'
+    with settings.hidden_var_f64(False):
+        assert settings.hidden_var_f64.value() is False
+    assert settings.hidden_var_f64.value() == 'auto'
     with settings.num_likelihood_samples(3):
         assert settings.num_likelihood_samples.value() == 3
         with settings.num_likelihood_samples(5):
