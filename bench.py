@@ -329,6 +329,35 @@ def b3_sparse_multivariate_step_ms(device):
             'hipgraph_note': 'not captured (host-side pieces in the prior conditional mean)'}
 
 
+def mfma_sustained(device):
+    """What the matrix cores of THIS chip deliver with nothing but MFMAs in flight (nsgp_mfma_rate_probe: a chip-filling grid
+    of register-only MFMA loops): {'f32' | 'f64' | 'i8': {'rate': TFLOP/s or TOP/s, 'clock_GHz': shader clock held under that
+    load}}.  The data-sheet peaks the `roofline` objects are priced against assume 2.4 GHz; under full matrix-core load the
+    chip holds ~2.1 GHz, so a GEMM that kept every matrix core busy all the time would reach rate / peak ~ 0.88, not 1."""
+    import numpy as np
+    from nsgp import _lib, ops
+    out = {}
+    wgs = 2048
+    buf = torch.zeros(8 * wgs, dtype=torch.int64, device=device)
+    sink = torch.zeros(4, dtype=torch.float32, device=device)
+    for name, kind, iters, ops_per in (('f32', 0, 400, 4096), ('f64', 1, 400, 2048), ('i8', 2, 800, 65536)):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best = None
+        for rep in range(3):
+            e0.record()
+            _lib.call('nsgp_mfma_rate_probe', kind, wgs, iters, ops._p(buf), ops._p(sink), ops._stream())
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1)
+            best = ms if best is None or ms < best else best
+        a = buf.cpu().numpy().reshape(-1, 2).astype(np.float64)
+        ok = a[:, 1] > 0
+        clk = float(np.median(a[ok, 0] / a[ok, 1]) * 0.1) if ok.any() else None          # cycles per 10 ns tick -> GHz
+        out[name] = {'rate': round(wgs * 4 * iters * 8 * ops_per / (best * 1e-3) / 1e12, 1),
+                     'clock_GHz': round(clk, 3) if clk else None}
+    return out
+
+
 def gibbs_chol_ms(device, with_cpu=True):
     """BASELINE B2 table + the N = 4096 figures as flat fields (the metric's second half) + the float64 MAP step."""
     table = build_chol_table(device, with_cpu=with_cpu)
@@ -768,6 +797,7 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12
+        sus = mfma_sustained(device)
         result = {
             # a "step" is one fwd+ELBO+bwd+Adam pass over a 4096-row minibatch.  Weak scaling: an N-GPU iteration is N
             # such passes (one per rank, global batch 4096 N) joined by one RCCL all-reduce, so value = N x iterations/s;
@@ -805,6 +835,10 @@ def main():
             'roofline': {'bound': 'mfma', 'kernel': 'gemm_kernel<float,128,128,*,*> (all f32 GEMM launches of a step)',
                          'achieved': round(achieved, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), **gemm_traffic(world, share),
+                         # context, not the contract's `peak`: the rate a register-only MFMA loop sustains on this chip, and
+                         # the clock it holds meanwhile (the 157.3 above assumes 2.4 GHz)
+                         'sustained_mfma_measured': sus['f32']['rate'], 'clock_GHz_under_mfma_load': sus['f32']['clock_GHz'],
+                         'frac_of_sustained': round(achieved / sus['f32']['rate'], 4),
                          'gemm_ms_per_step': round(gemm_ms / nprof, 3),
                          'gemm_launches_per_step': gemm_launches // nprof,
                          'algorithmic_gflop_per_step': round(gemm_flops / nprof / 1e9, 2),
@@ -815,7 +849,9 @@ def main():
             'f64acc_projection': ({'ms_per_step': round(acc_ms / nprof, 3), 'launches_per_step': acc_launches // nprof,
                                    'algorithmic_gflop_per_step': round(acc_flops / nprof / 1e9, 2),
                                    'achieved': round(acc_flops / (acc_ms * 1e-3) / 1e12, 2), 'peak': MFMA_F64_PEAK_TFLOPS,
-                                   'unit': 'TFLOP/s', 'frac': round(acc_flops / (acc_ms * 1e-3) / 1e12 / MFMA_F64_PEAK_TFLOPS, 4)}
+                                   'unit': 'TFLOP/s', 'frac': round(acc_flops / (acc_ms * 1e-3) / 1e12 / MFMA_F64_PEAK_TFLOPS, 4),
+                                   'sustained_mfma_measured': sus['f64']['rate'],
+                                   'frac_of_sustained': round(acc_flops / (acc_ms * 1e-3) / 1e12 / sus['f64']['rate'], 4)}
                                   if acc_launches else None),
             # the same projection on the int8 matrix cores (settings.whiten_matmul_i8, default): exact digit-plane products.
             # `achieved` counts the int8 operations actually issued (14 plane products per multiply-add of the float64
@@ -825,7 +861,9 @@ def main():
                                'algorithmic_gflop_per_step': round(i8_flops / nprof / 1e9, 2),
                                'achieved': round(I8_PLANE_PRODUCTS * i8_flops / (i8_ms * 1e-3) / 1e12, 1), 'peak': MFMA_I8_PEAK_TOPS,
                                'unit': 'TOP/s (int8)', 'frac': round(I8_PLANE_PRODUCTS * i8_flops / (i8_ms * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS, 4),
-                               'f64_equivalent_TFLOPs': round(i8_flops / (i8_ms * 1e-3) / 1e12, 2)}
+                               'f64_equivalent_TFLOPs': round(i8_flops / (i8_ms * 1e-3) / 1e12, 2),
+                               'sustained_mfma_measured': sus['i8']['rate'],
+                               'frac_of_sustained': round(I8_PLANE_PRODUCTS * i8_flops / (i8_ms * 1e-3) / 1e12 / sus['i8']['rate'], 4)}
                               if i8_launches else None),
         }
         if world == 1:

@@ -31,6 +31,14 @@ extern "C" {
 int nsgp_abi_version(void);                 /* bumps when a signature changes */
 const char* nsgp_build_arch(void);          /* "gfx950" */
 
+/* Measurement aid (bench.py's roofline context; no reference counterpart): the matrix-core rate THIS chip sustains.  A
+ * grid of `workgroups` x 4 waves issues iters x 8 independent register-only MFMAs per wave -- kind 0: v_mfma_f32_32x32x2_f32,
+ * 1: v_mfma_f64_16x16x4_f64, 2: v_mfma_i32_32x32x32_i8 -- and every wave writes (shader-clock cycles, 100 MHz wall ticks) it
+ * spent to out[2 (4 wg + wave) + {0, 1}].  cycles / ticks x 100 MHz = the clock held under full matrix-core load (MI355X:
+ * ~2.1 GHz against the 2.4 GHz of the data-sheet peaks); operations / launch time = the rate no GEMM on this chip exceeds.
+ * out: device, 8 x workgroups uint64; sink: device float (never written); iters: a positive multiple of 16. */
+int nsgp_mfma_rate_probe(int kind, int64_t workgroups, int iters, uint64_t* out, float* sink, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * K1  Diagonal Gibbs kernel (Rasmussen & Williams eq. 4.32)
  *     K[i,j] = os * prod_d sqrt(2 l1[d,i] l2[d,j] / (l1[d,i]^2 + l2[d,j]^2))

@@ -31,6 +31,7 @@
 // conflict-free ds_read_b128 per lane; the stages are filled by LDS-DMA (global_load_lds_dwordx4: a K-step's block is one
 // contiguous run in memory, so no registers are spent on staging; NSGP_I8_DMA=0 builds the register-staged form); the K
 // planes of a K-step stay in registers while the W planes stream through; two workgroups per CU.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -150,6 +151,13 @@ __global__ __launch_bounds__(256, 2) void i8_proj_kernel(const signed char* __re
     const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 32;
     const int64_t bb = blockIdx.y;
     const int tiles_m = (int)(Mp / I8_BM);
+    // Anatomy of the two launches of a headline step (0.441 ms; switches that skipped the MFMAs / the staging / both, r3m):
+    // staging alone 0.345, MFMAs + fragment reads alone 0.363, neither -- first-stage latency, barriers, the float64 Horner
+    // epilogue and the stores of 5120 + 1024 short workgroups -- 0.187 ms.  The K loop moves 28 KB into LDS per 112 MFMAs
+    // (2.6 GB per launch, 7.4 TB/s): larger tiles (128 x 128 with eight waves) are the lever, not the tile order.
+    // (Tried and dropped: an XCD-grouped order -- workgroup 8 q + x, which the hardware places on XCD x, walking all row tiles of
+    // column tiles x, x + 8, ... back to back so that a column tile's Kzx planes enter that L2 once: 0.441 -> 0.534 ms per
+    // headline step, like the same experiment on the float32 GEMM.)
     const int bm = tiles_m - 1 - (int)blockIdx.x / tiles_n;          // long K ranges first
     const int bn = (int)blockIdx.x % tiles_n;
     const int64_t m0 = (int64_t)bm * I8_BM, n0 = (int64_t)bn * I8_BN;

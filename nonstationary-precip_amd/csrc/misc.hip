@@ -168,6 +168,58 @@ int philox_impl(uint64_t seed, uint64_t stream_id, const int64_t* step_dev, int6
     return nsgp_launch_status();
 }
 
+// ---- sustained matrix-core rate of THIS chip under load (bench.py's roofline context) ----------------------------------
+// Every wave of a chip-filling grid issues `iters` x 8 independent register-only MFMAs (no memory, no LDS) and stamps the
+// shader clock (s_memtime) and the 100 MHz wall clock (s_memrealtime) around them: the ratio is the clock the chip holds
+// while all matrix cores are busy (MI355X: ~2.1 GHz, not the 2.4 GHz the data-sheet peak is quoted at), and flops / time of
+// the launch is the rate no GEMM can exceed.  KIND 0: v_mfma_f32_32x32x2_f32, 1: v_mfma_f64_16x16x4_f64, 2: v_mfma_i32_32x32x32_i8.
+template <int KIND>
+__global__ __launch_bounds__(256) void mfma_rate_probe_kernel(int iters, unsigned long long* __restrict__ out, float* __restrict__ sink) {
+    typedef float v16f __attribute__((ext_vector_type(16)));
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    typedef int v16i __attribute__((ext_vector_type(16)));
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    float keep = 0.f;
+    if constexpr (KIND == 0) {
+        v16f acc[8];
+        for (int q = 0; q < 8; ++q) for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+        const float a = 1.0f + threadIdx.x * 1e-3f, b = 1.0f - threadIdx.x * 1e-3f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[q], 0, 0, 0);
+        }
+        for (int q = 0; q < 8; ++q) keep += acc[q][0];
+    } else if constexpr (KIND == 1) {
+        v4d acc[8];
+        for (int q = 0; q < 8; ++q) for (int r = 0; r < 4; ++r) acc[q][r] = 0.0;
+        const double a = 1.0 + threadIdx.x * 1e-3, b = 1.0 - threadIdx.x * 1e-3;
+        for (int it = 0; it < iters; it += 16) {         // 16 rounds per trip: hipcc moves the float64 accumulators between
+#pragma unroll                                            // AGPRs and VGPRs at the loop's back edge (128 copies)
+            for (int u = 0; u < 16; ++u)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[q], 0, 0, 0);
+        }
+        for (int q = 0; q < 8; ++q) keep += (float)acc[q][0];
+    } else {
+        v16i acc[8];
+        for (int q = 0; q < 8; ++q) for (int r = 0; r < 16; ++r) acc[q][r] = 0;
+        const v4i a = {(int)threadIdx.x, 0x01010101, 0x01020304, 0x7f7f7f7f}, b = {0x01010101, (int)threadIdx.x, 0x04030201, 0x01010101};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc[q], 0, 0, 0);
+        }
+        for (int q = 0; q < 8; ++q) keep += (float)acc[q][0];
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x & 63) == 0) {
+        const size_t wv = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+        out[2 * wv] = t1 - t0;
+        out[2 * wv + 1] = r1 - r0;
+    }
+    if (keep == 123.456f) sink[0] = keep;                 // keeps the accumulators alive
+}
+
 }  // namespace
 
 extern "C" {
@@ -219,4 +271,15 @@ int nsgp_adam_step_f32(float* p, const float* g, float* exp_avg, float* exp_avg_
     return nsgp_launch_status();
 }
 
+int nsgp_mfma_rate_probe(int kind, int64_t workgroups, int iters, uint64_t* out, float* sink, void* stream) {
+    // out: 2 x 4 x workgroups uint64 (per wave: shader-clock cycles, 100 MHz ticks); one wave issues iters x 8 MFMAs
+    if (kind < 0 || kind > 2) return -1; if (workgroups <= 0 || workgroups > 1048576) return -2; if (iters <= 0 || iters % 16) return -3;
+    if (!out) return -4; if (!sink) return -5;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long* o = (unsigned long long*)out;
+    if (kind == 0) hipLaunchKernelGGL((mfma_rate_probe_kernel<0>), dim3((unsigned)workgroups), dim3(256), 0, st, iters, o, sink);
+    else if (kind == 1) hipLaunchKernelGGL((mfma_rate_probe_kernel<1>), dim3((unsigned)workgroups), dim3(256), 0, st, iters, o, sink);
+    else hipLaunchKernelGGL((mfma_rate_probe_kernel<2>), dim3((unsigned)workgroups), dim3(256), 0, st, iters, o, sink);
+    return nsgp_launch_status();
+}
 }  // extern "C"
