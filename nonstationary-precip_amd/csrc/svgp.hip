@@ -108,6 +108,34 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const T* __restrict__ A, co
 //   row  M+1          : out_1     = sum_j g[b,j]                               (constant mean / bias gradient)
 //   rows M+2 .. M+1+D : out_x[d]  = sum_j x[b,j,d] g[b,j]                      (linear-mean weight gradient)
 // out_1 / out_x are per batch, or summed over the batch when the mean parameters are shared (`shared`).
+// sum of q[0..n) by one 256-thread workgroup: 16-byte loads, four of them in flight per lane per trip (block-reduced; lds: 4
+// elements)
+template <typename T> __device__ __forceinline__ T strided_sum4(const T* __restrict__ q, int64_t n, T* lds) {
+    constexpr int V = 16 / sizeof(T);
+    T a0 = T(0), a1 = T(0), a2 = T(0), a3 = T(0);
+    int64_t j = 0;
+    if ((uintptr_t)q % 16 == 0) {
+        auto ld = [&](int64_t at) __attribute__((always_inline)) {
+            T v = T(0);
+            if constexpr (sizeof(T) == 4) { const float4 t = *reinterpret_cast<const float4*>(q + at); v = (t.x + t.y) + (t.z + t.w); }
+            else { const double2 t = *reinterpret_cast<const double2*>(q + at); v = t.x + t.y; }
+            return v;
+        };
+        const int64_t step = 256 * V;
+        for (j = (int64_t)threadIdx.x * V; j + 3 * step + V <= n; j += 4 * step) {
+            a0 += ld(j); a1 += ld(j + step); a2 += ld(j + 2 * step); a3 += ld(j + 3 * step);
+        }
+        for (; j + V <= n; j += step) a0 += ld(j);
+        // ragged end: elements [n - n % V, n) by the first lanes
+        const int64_t tail0 = n - n % V;
+        if ((int64_t)threadIdx.x < n - tail0) a1 += q[tail0 + threadIdx.x];
+    } else {
+        for (j = threadIdx.x; j + 768 < n; j += 1024) { a0 += q[j]; a1 += q[j + 256]; a2 += q[j + 512]; a3 += q[j + 768]; }
+        for (; j < n; j += 256) a0 += q[j];
+    }
+    return block_sum_256((a0 + a1) + (a2 + a3), lds);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void rowdot_affine_kernel(const T* __restrict__ A, const T* __restrict__ g,
                                                             const T* __restrict__ gv, const T* __restrict__ x,
@@ -123,34 +151,35 @@ __global__ __launch_bounds__(256) void rowdot_affine_kernel(const T* __restrict_
         constexpr int V = 16 / sizeof(T);
         const bool vec = (n % V == 0) && ((uintptr_t)row % 16 == 0) && ((uintptr_t)gb % 16 == 0);
         if (vec) {
-            int64_t j = (int64_t)threadIdx.x * V;
-            if constexpr (sizeof(T) == 4) {
-                // four independent 16-byte loads of each operand in flight per lane (one per iteration left the row read at
-                // 2 TB/s: 85 us for the 1024 x 40960 A of the headline step's last layer)
-                T a1 = T(0), a2 = T(0), a3 = T(0);
-                for (; j + 3 * 256 * V < n; j += 4 * 256 * V) {
-                    const float4 p0 = *reinterpret_cast<const float4*>(row + j), q0 = *reinterpret_cast<const float4*>(gb + j);
-                    const float4 p1 = *reinterpret_cast<const float4*>(row + j + 256 * V), q1 = *reinterpret_cast<const float4*>(gb + j + 256 * V);
-                    const float4 p2 = *reinterpret_cast<const float4*>(row + j + 512 * V), q2 = *reinterpret_cast<const float4*>(gb + j + 512 * V);
-                    const float4 p3 = *reinterpret_cast<const float4*>(row + j + 768 * V), q3 = *reinterpret_cast<const float4*>(gb + j + 768 * V);
-                    acc += p0.x * q0.x + p0.y * q0.y + p0.z * q0.z + p0.w * q0.w;
-                    a1 += p1.x * q1.x + p1.y * q1.y + p1.z * q1.z + p1.w * q1.w;
-                    a2 += p2.x * q2.x + p2.y * q2.y + p2.z * q2.z + p2.w * q2.w;
-                    a3 += p3.x * q3.x + p3.y * q3.y + p3.z * q3.z + p3.w * q3.w;
+            // Chunks of 256 lanes x 16 bytes, walked from a start that differs from row to row: rows are n elements apart
+            // (160 KB at the headline's last layer, a multiple of the memory channels' interleave), so workgroups that all
+            // begin at column 0 march through the SAME channel together.  Eight chunks in flight per lane.
+            const int64_t nch = (n + 256 * V - 1) / (256 * V);
+            const int64_t c0 = i % nch;
+            T a1 = T(0), a2 = T(0), a3 = T(0);
+            auto chunk = [&](int64_t t, T& dst) __attribute__((always_inline)) {
+                int64_t c = c0 + t;
+                if (c >= nch) c -= nch;
+                const int64_t j = (c * 256 + threadIdx.x) * V;
+                if (j < n) {
+                    if constexpr (sizeof(T) == 4) {
+                        const float4 a = *reinterpret_cast<const float4*>(row + j);
+                        const float4 q = *reinterpret_cast<const float4*>(gb + j);
+                        dst += a.x * q.x + a.y * q.y + a.z * q.z + a.w * q.w;
+                    } else {
+                        const double2 a = *reinterpret_cast<const double2*>(row + j);
+                        const double2 q = *reinterpret_cast<const double2*>(gb + j);
+                        dst += a.x * q.x + a.y * q.y;
+                    }
                 }
-                acc = (acc + a1) + (a2 + a3);
+            };
+            int64_t t = 0;
+            for (; t + 7 < nch; t += 8) {
+                chunk(t, acc); chunk(t + 1, a1); chunk(t + 2, a2); chunk(t + 3, a3);
+                chunk(t + 4, acc); chunk(t + 5, a1); chunk(t + 6, a2); chunk(t + 7, a3);
             }
-            for (; j < n; j += 256 * V) {
-                if constexpr (sizeof(T) == 4) {
-                    const float4 a = *reinterpret_cast<const float4*>(row + j);
-                    const float4 q = *reinterpret_cast<const float4*>(gb + j);
-                    acc += a.x * q.x + a.y * q.y + a.z * q.z + a.w * q.w;
-                } else {
-                    const double2 a = *reinterpret_cast<const double2*>(row + j);
-                    const double2 q = *reinterpret_cast<const double2*>(gb + j);
-                    acc += a.x * q.x + a.y * q.y;
-                }
-            }
+            for (; t < nch; ++t) chunk(t, acc);
+            acc = (acc + a1) + (a2 + a3);
         } else {
             for (int64_t j = threadIdx.x; j < n; j += 256) acc += row[j] * gb[j];
         }
@@ -161,9 +190,10 @@ __global__ __launch_bounds__(256) void rowdot_affine_kernel(const T* __restrict_
     const int e = (int)(i - M);
     if (e == 0) {
         if (!gv) return;
+        // (the virtual rows are ONE workgroup each: with a dependent-latency loop of n / 256 scalar loads they, not the M
+        // rows of A, set the launch's duration -- 87 of 100 us at n = 40960.  Four independent loads per lane per trip.)
         const T* q = gv + b * n;
-        for (int64_t j = threadIdx.x; j < n; j += 256) acc += q[j];
-        acc = block_sum_256(acc, lds);
+        acc = strided_sum4(q, n, lds);
         if (threadIdx.x == 0) out_gv[b] = acc;
         return;
     }
@@ -172,14 +202,25 @@ __global__ __launch_bounds__(256) void rowdot_affine_kernel(const T* __restrict_
     const int64_t b1 = shared ? batch : b + 1;
     for (int64_t bb = b; bb < b1; ++bb) {
         const T* gb = g + bb * n;
+        T a0 = T(0), a1 = T(0), a2 = T(0), a3 = T(0);
+        int64_t j = threadIdx.x;
         if (e == 1) {
-            for (int64_t j = threadIdx.x; j < n; j += 256) acc += gb[j];
-        } else {
-            const T* xc = x + bb * sxb + (e - 2);
-            for (int64_t j = threadIdx.x; j < n; j += 256) acc += xc[j * D] * gb[j];
+            acc += strided_sum4(gb, n, lds);             // (block-reduced already: every lane holds the sum)
+            __syncthreads();
+            continue;
         }
+        const T* xc = x + bb * sxb + (e - 2);
+        for (; j + 1792 < n; j += 2048) {                // eight (g, x) pairs in flight per lane
+            T gq[8], xq[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { gq[u] = gb[j + 256 * u]; xq[u] = xc[(j + 256 * u) * D]; }
+            a0 += xq[0] * gq[0] + xq[4] * gq[4]; a1 += xq[1] * gq[1] + xq[5] * gq[5];
+            a2 += xq[2] * gq[2] + xq[6] * gq[6]; a3 += xq[3] * gq[3] + xq[7] * gq[7];
+        }
+        for (; j < n; j += 256) a0 += xc[j * D] * gb[j];
+        acc += (a0 + a1) + (a2 + a3);
     }
-    acc = block_sum_256(acc, lds);
+    if (e != 1) acc = block_sum_256(acc, lds);
     if (threadIdx.x == 0) {
         if (e == 1) out_1[shared ? 0 : b] = acc;
         else out_x[(shared ? 0 : b) * D + (e - 2)] = acc;
