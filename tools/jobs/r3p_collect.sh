@@ -3,6 +3,7 @@
 set -e
 R=$(pwd)
 O=$R/gpurun_out/r3p
+if [ -z "$GRAFT_REPO_ROOT" ] && [ ! -d $O ]; then echo "no $O"; exit 1; fi
 P=$R/profiles/r03
 mkdir -p $P
 for f in bench_default_run bench_profiled bench_rank_share_2 bench_rank_share_4 bench_rank_share_8 bench_cfg5_f32 bench_cfg5_bf16 bench_rehearse_rccl; do
@@ -13,7 +14,7 @@ python tools/step_timeline.py $(ls $O/kt/*/*kernel_trace.csv | tail -1) > $P/ste
 python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write --match gemm_kernel > $P/gemm_hbm_pmc.txt
 python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write --match i8_ >> $P/gemm_hbm_pmc.txt
 python tools/pmc_mfma_summary.py $O/pmc_sq --match gemm_kernel potrf i8_proj > $P/gemm_mfma_pmc.txt
-python tools/gemm_traffic.py $O/pmc_fetch $O/pmc_write > $P/gemm_traffic.json
+cp $O/gemm_traffic.json $P/gemm_traffic.json
 python tools/build_chol_profile_summary.py $O/bc_kt --write $O/bc_pmc_write --fetch $O/bc_pmc_fetch --sq $O/bc_pmc_sq --sizes 4096,16384 > $P/build_chol_profile.txt
 cp $(ls $O/bc_kt/*/*kernel_stats.csv | tail -1) $P/build_chol_kernel_stats.csv
 grep -v amdgpu $O/build_chol_probe_plain.log > $P/build_chol_probe.log

@@ -6,15 +6,20 @@ O=$R/gpurun_out/r3p
 rm -rf $O
 mkdir -p $O
 cd $R
-python bench.py > $O/bench_default_run.json.log 2> $O/bench_default_run.err
-echo "bench done"
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --no-cpu-baseline --no-build-chol"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- $B --steps 30 --warmup 5 > $O/bench_profiled.json.log 2>&1
+# PMC passes first: roofline.traffic of the bench lines below comes from the hash-gated JSON they produce
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- $B --steps 3 --warmup 1 --no-graph > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- $B --steps 3 --warmup 1 --no-graph > $O/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT \
     --kernel-trace --output-format csv -d $O/pmc_sq -- $B --steps 3 --warmup 1 --no-graph > $O/pmc_sq.log 2>&1
+cd $R
+python tools/gemm_traffic.py $O/pmc_fetch $O/pmc_write > $O/gemm_traffic.json
+cp $O/gemm_traffic.json $R/profiles/r03/gemm_traffic.json
+python bench.py > $O/bench_default_run.json.log 2> $O/bench_default_run.err
+echo "bench done"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- $B --steps 30 --warmup 5 > $O/bench_profiled.json.log 2>&1
 echo "bench profiles done"
 # second half of the metric: Gibbs build + potrf at N = 4096 / 16384
 P="python3 $R/tools/build_chol_probe.py 4096 16384"
