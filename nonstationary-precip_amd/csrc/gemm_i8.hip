@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void i8_proj_kernel(const signed char* __re
     const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 32;
     const int64_t bb = blockIdx.y;
     const int tiles_m = (int)(Mp / I8_BM);
-    // Anatomy of the two launches of a headline step (0.441 ms; switches that skipped the MFMAs / the staging / both, r3m):
+    // Anatomy of the two launches of a headline step (0.441 ms; switches that skipped the MFMAs / the staging / both):
     // staging alone 0.345, MFMAs + fragment reads alone 0.363, neither -- first-stage latency, barriers, the float64 Horner
     // epilogue and the stores of 5120 + 1024 short workgroups -- 0.187 ms.  The K loop moves 28 KB into LDS per 112 MFMAs
     // (2.6 GB per launch, 7.4 TB/s): larger tiles (128 x 128 with eight waves) are the lever, not the tile order.
