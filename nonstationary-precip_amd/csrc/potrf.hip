@@ -882,7 +882,8 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ A, int6
                                                          int32_t* __restrict__ info, int64_t nslab, int pre,
                                                          int64_t wcols) {
     extern __shared__ __attribute__((aligned(16))) unsigned char panel_smem[];
-    const int64_t blk = blockIdx.x, b = blockIdx.y;
+    const int64_t lin = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;     // matrix fastest: see potrf_inv_step_kernel
+    const int64_t blk = lin / gridDim.y, b = lin % gridDim.y;
     if (blk < nslab) {
         // bit 1 of `pre`: the round-1 panel (NSGP_POTRF_PANEL=1), kept for A/B timing
         if (pre & 2) panel_body<T>(panel_smem, A, n, lda, sA, j0, wsL, npanels, info, blk, b, (pre & 1) != 0);
@@ -1210,8 +1211,13 @@ __global__ __launch_bounds__(256) void potrf_inv_step_kernel(T* __restrict__ A, 
                                                              int64_t sX, int64_t nslab, int64_t nprow, int64_t nsyrk,
                                                              int pre, int64_t wcols, float* __restrict__ X32) {
     extern __shared__ __attribute__((aligned(16))) unsigned char panel_smem[];
-    int64_t blk = blockIdx.x;
-    const int64_t b = blockIdx.y;
+    // Workgroups are dispatched x fastest, then y.  With the matrix on y, a batched chain whose launch needs more than one
+    // round (3 x 1024^2 in the DSVI step: up to 405 workgroups at ONE per CU, 142 KB of LDS in float64) started the panel
+    // workgroups of matrices 1, 2 -- the serial chain -- behind all of matrix 0's update tiles: 34 us launches against 20.
+    // Linear id -> (work item, matrix) with the matrix fastest: every matrix's panel / slab / row-block workgroups go first.
+    const int64_t lin = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+    int64_t blk = lin / gridDim.y;
+    const int64_t b = lin % gridDim.y;
     if (blk < nslab) { panel_body2<T>(panel_smem, A, n, lda, sA, j0, wsL, npanels, info, blk, b, pre != 0); return; }
     blk -= nslab;
     if (blk < nprow) { prow_body<T>(panel_smem, A, n, lda, sA, j0, X, ldx, sX, blk, b, pre != 0, X32); return; }
