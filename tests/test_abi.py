@@ -89,3 +89,40 @@ def test_potrf_trtri_rejects_bad_arguments_with_error_codes_not_faults():
         assert call(name, X=None) == -7
         assert call(name, ldx=1) == -8
         assert call(name, n=0) == 0 and call(name, batch=0) == 0
+
+
+def test_round3_entry_points_validate_their_arguments_on_the_host():
+    """The int8 projection entry points, their planner queries and the matrix-core rate probe reject bad arguments with the
+    index of the offending one before any launch (safe without a GPU), and the planner queries answer from sizes alone."""
+    import nsgp
+    lib = nsgp.load_library()
+    buf = (ctypes.c_double * 64)()
+    P = lambda o: ctypes.cast(o, ctypes.c_void_p)
+    b = P(buf)
+    # planner queries (csrc/gemm_i8.hip: 128-row tiles, 64-column tiles, 32-deep k-blocks, 16-byte pieces)
+    assert lib.nsgp_i8_supported(1024) == 1 and lib.nsgp_i8_supported(4096) == 1 and lib.nsgp_i8_supported(4097) == 0
+    assert lib.nsgp_i8_tiles(1024) == 8 and lib.nsgp_i8_tiles(1000) == 8 and lib.nsgp_i8_tiles(0) == 0
+    assert lib.nsgp_i8_w_planes_bytes(2, 1024) == 2 * 5 * 32 * 2 * 1024 * 16
+    assert lib.nsgp_i8_k_planes_bytes(1, 1024, 4096, 4) == 4 * 32 * 2 * 4096 * 16
+    assert lib.nsgp_i8_k_planes_bytes(1, 1024, 4096, 3) == 0                     # only 4 or 5 planes exist
+    # slicing W
+    assert lib.nsgp_i8_slice_w_f64(None, 1, 128, b, b, None) == -1
+    assert lib.nsgp_i8_slice_w_f64(b, -1, 128, b, b, None) == -2
+    assert lib.nsgp_i8_slice_w_f64(b, 1, 5000, b, b, None) == -3
+    assert lib.nsgp_i8_slice_w_f64(b, 1, 128, None, b, None) == -4
+    assert lib.nsgp_i8_slice_w_f64(b, 1, 128, b, None, None) == -5
+    assert lib.nsgp_i8_slice_w_f64(b, 0, 128, b, b, None) == 0
+    # the product
+    ok = [b, b, b, b, 4, None, 1, 128, 64, b, None, b, 1, 0, None]
+    bad = lambda i, v: lib.nsgp_svgp_tri_gemm_colstats_i8(*[v if k == i else a for k, a in enumerate(ok)])
+    assert bad(0, None) == -1 and bad(1, None) == -2 and bad(2, None) == -3 and bad(3, None) == -4
+    assert bad(4, 3) == -5 and bad(4, 6) == -5
+    assert bad(6, -1) == -6 and bad(7, 5000) == -7 and bad(8, -1) == -8 and bad(9, None) == -9 and bad(11, None) == -11
+    assert bad(12, 0) == -12                                                      # fewer partial rows than tile rows
+    assert bad(8, 0) == 0 and bad(6, 0) == 0
+    # the rate probe
+    assert lib.nsgp_mfma_rate_probe(3, 256, 16, b, b, None) == -1
+    assert lib.nsgp_mfma_rate_probe(0, 0, 16, b, b, None) == -2
+    assert lib.nsgp_mfma_rate_probe(0, 256, 15, b, b, None) == -3                # iterations: a multiple of 16
+    assert lib.nsgp_mfma_rate_probe(0, 256, 16, None, b, None) == -4
+    assert lib.nsgp_mfma_rate_probe(0, 256, 16, b, None, None) == -5
