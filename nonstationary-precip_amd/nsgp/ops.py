@@ -526,13 +526,17 @@ def scale_diag_(P, factor):
     return P
 
 
-def cast(t, dtype):
-    """float32 <-> float64 copy on the current stream (row-major, any leading shape)."""
+def cast(t, dtype, out=None):
+    """float32 <-> float64 copy on the current stream (row-major, any leading shape).  `out`: a contiguous tensor of the
+    target dtype and the same number of elements to write into (e.g. a slice of a batched buffer) instead of a new one."""
     _chk(t)
-    if t.dtype == dtype:
+    if t.dtype == dtype and out is None:
         return t
     t = _c(t)
-    out = torch.empty(t.shape, dtype=dtype, device=t.device)
+    if out is None:
+        out = torch.empty(t.shape, dtype=dtype, device=t.device)
+    elif out.dtype != dtype or out.numel() != t.numel() or not out.is_contiguous() or out.device != t.device or t.dtype == dtype:
+        raise BackendError('cast(out=...): contiguous tensor of the target dtype with as many elements, on the same device')
     cols = t.shape[-1] if t.dim() else 1
     rows = t.numel() // max(cols, 1)
     name = 'nsgp_cast_f64_to_f32' if dtype == torch.float32 else 'nsgp_cast_f32_to_f64'

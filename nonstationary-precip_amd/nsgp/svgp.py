@@ -94,7 +94,10 @@ class WhitenFn(torch.autograd.Function):
                     dst.append(Wbar[off:off + b])
                     src.append(gouts[gi])
                 off += b
-            if dst:
+            if dst and all(g.dtype == torch.float32 and g.is_cuda for g in src) and Wbar.dtype == torch.float64:
+                for d_, s_ in zip(dst, src):             # one cast launch per layer: the multi-tensor copy of three 1024^2
+                    ops.cast(s_, torch.float64, out=d_)  # matrices took 27 us (few, large tensors), these take 5 + 8
+            elif dst:
                 torch._foreach_copy_(dst, src)
         if ctx.chol_bwd_f64:
             Wb, Wc = Wbar.contiguous(), W64
