@@ -322,7 +322,8 @@ int nsgp_svgp_colstats_finalize_affine_p64_f32(const double* part_dot, const dou
  * (behind /root/reference/models/dgps.py:44-51) at 64x the float64 MFMA rate per multiply-add.
  *   nsgp_i8_slice_w_f64:  W:(batch,M,M) float64, lower triangle used -> Wd (nsgp_i8_w_planes_bytes), wscale:(batch,M)
  *   nsgp_i8_rbf_build_f32: Z:(batch,M,D), x:(n,D) (x_batch_stride 0) or (batch,n,D), ls:(batch,D), os:(batch,), D <= 4
- *                          -> Kd (nsgp_i8_k_planes_bytes), kscale:(batch,)
+ *                          -> Kd (nsgp_i8_k_planes_bytes), kscale:(batch,); Kzx_f32: optional (batch,M,n) float32 Kzx rounded
+ *                          from the float64 values (what the backward's Wbar = tril(Abar Kzx^T) reads), NULL to skip
  *   nsgp_svgp_tri_gemm_colstats_i8: Y:(batch,M,n) float32 and the column-statistic partials of
  *       nsgp_svgp_tri_gemm_colstats (nsgp_i8_tiles(M) = ceil(M/128) tile rows; float32, or float64 with partials_f64 != 0),
  *       taken from the float64 values.  rowvec may be NULL (then part_dot is not written).
@@ -334,7 +335,8 @@ size_t nsgp_i8_k_planes_bytes(int64_t batch, int64_t M, int64_t n, int planes);
 size_t nsgp_i8_tiles(int64_t M);
 int nsgp_i8_slice_w_f64(const double* W, int64_t batch, int64_t M, void* Wd, double* wscale, void* stream);
 int nsgp_i8_rbf_build_f32(const float* Z, const float* x, int64_t x_batch_stride, const float* ls, const float* os,
-                          int64_t batch, int64_t M, int64_t n, int D, int planes, void* Kd, double* kscale, void* stream);
+                          int64_t batch, int64_t M, int64_t n, int D, int planes, void* Kd, double* kscale, float* Kzx_f32,
+                          void* stream);
 int nsgp_svgp_tri_gemm_colstats_i8(const void* Wd, const double* wscale, const void* Kd, const double* kscale,
                                    int planes, const float* rowvec, int64_t batch, int64_t M, int64_t n, float* Y,
                                    void* part_dot, void* part_sq, int64_t part_rows, int partials_f64, void* stream);

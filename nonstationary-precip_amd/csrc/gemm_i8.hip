@@ -88,7 +88,8 @@ template <int D, int SK>
 __global__ __launch_bounds__(256) void i8_rbf_build_kernel(const float* __restrict__ Z, const float* __restrict__ x, int64_t sx,
                                                            const float* __restrict__ ls, const float* __restrict__ os,
                                                            int64_t M, int64_t n, int64_t np, int64_t KB,
-                                                           signed char* __restrict__ Kd, double* __restrict__ ksc) {
+                                                           signed char* __restrict__ Kd, double* __restrict__ ksc,
+                                                           float* __restrict__ Kf) {
     const int64_t b = blockIdx.z, kb = blockIdx.y;
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     __shared__ double zs[32][D];
@@ -119,7 +120,12 @@ __global__ __launch_bounds__(256) void i8_rbf_build_kernel(const float* __restri
             double r2 = 0.0;
 #pragma unroll
             for (int d = 0; d < D; ++d) { const double df = zs[kk][d] - xs[d]; r2 = __builtin_fma(df, df, r2); }
-            double t = (j < n && kb * 32 + kk < M) ? sc * t_fexp<double>(-0.5 * r2) : 0.0;
+            const bool in = j < n && kb * 32 + kk < M;
+            const double ev = in ? t_fexp<double>(-0.5 * r2) : 0.0;
+            // the float32 Kzx the backward pass needs for Wbar = tril(Abar Kzx^T), rounded from the float64 value (the forward
+            // pass itself never reads it): saves the backward's own build launch
+            if (Kf && in) Kf[(b * M + kb * 32 + kk) * n + j] = (float)(osd * ev);
+            double t = sc * ev;
 #pragma unroll
             for (int s = 0; s < SK; ++s) {
                 const double dg = rint(t);
@@ -350,7 +356,8 @@ int nsgp_i8_slice_w_f64(const double* W, int64_t batch, int64_t M, void* Wd, dou
 }
 
 int nsgp_i8_rbf_build_f32(const float* Z, const float* x, int64_t x_batch_stride, const float* ls, const float* os,
-                          int64_t batch, int64_t M, int64_t n, int D, int planes, void* Kd, double* kscale, void* stream) {
+                          int64_t batch, int64_t M, int64_t n, int D, int planes, void* Kd, double* kscale, float* Kzx_f32,
+                          void* stream) {
     if (planes != 4 && planes != 5) return -10;
     if (!Z) return -1; if (!x) return -2; if (x_batch_stride < 0) return -3; if (!ls) return -4; if (!os) return -5;
     if (batch < 0) return -6; if (M < 0 || !nsgp_i8_supported(M > 0 ? M : 1)) return -7; if (n < 0) return -8;
@@ -361,7 +368,7 @@ int nsgp_i8_rbf_build_f32(const float* Z, const float* x, int64_t x_batch_stride
     dim3 grid((unsigned)cdiv64(np, 256), (unsigned)KB, (unsigned)batch);
     hipStream_t st = (hipStream_t)stream;
     signed char* kd = (signed char*)Kd;
-#define NSGP_I8_BUILD(DD, SS) hipLaunchKernelGGL((i8_rbf_build_kernel<DD, SS>), grid, dim3(256), 0, st, Z, x, x_batch_stride, ls, os, M, n, np, KB, kd, kscale)
+#define NSGP_I8_BUILD(DD, SS) hipLaunchKernelGGL((i8_rbf_build_kernel<DD, SS>), grid, dim3(256), 0, st, Z, x, x_batch_stride, ls, os, M, n, np, KB, kd, kscale, Kzx_f32)
     if (planes == 4) {
         switch (D) { case 1: NSGP_I8_BUILD(1, 4); break; case 2: NSGP_I8_BUILD(2, 4); break; case 3: NSGP_I8_BUILD(3, 4); break;
                      default: NSGP_I8_BUILD(4, 4); break; }

@@ -613,9 +613,10 @@ def svgp_kzx_fusable(W64f, Z, x, n):
     return bool(_lib.load().nsgp_svgp_kzx_gemm_supported(_p(W64f), M, n, batch, D))
 
 
-def _project_a_i8(W64f, kZ, kx, kls, kos, m, A, part_dot, part_sq, T, p64, planes, flops):
+def _project_a_i8(W64f, kZ, kx, kls, kos, m, A, part_dot, part_sq, T, p64, planes, flops, kzx_out=None):
     """A = W Kzx as the exact int8 digit-plane product (csrc/gemm_i8.hip): digit planes of W and of Kzx (evaluated in
-    float64 from Z, x, ls, os), then the product with its column-statistic partials (T tile rows per batch element)."""
+    float64 from Z, x, ls, os), then the product with its column-statistic partials (T tile rows per batch element).
+    kzx_out: a list that receives the float32 Kzx (b, M, n) the plane-build kernel writes along (for the backward pass)."""
     lib = _lib.load()
     batch, M, D = kZ.shape
     n = kx.shape[-2]
@@ -624,15 +625,18 @@ def _project_a_i8(W64f, kZ, kx, kls, kos, m, A, part_dot, part_sq, T, p64, plane
     Kd = torch.empty(int(lib.nsgp_i8_k_planes_bytes(batch, M, n, planes)), dtype=torch.uint8, device=dev)
     wsc = torch.empty((batch, M), dtype=torch.float64, device=dev)
     ksc = torch.empty((batch,), dtype=torch.float64, device=dev)
+    K32 = torch.empty((batch, M, n), dtype=torch.float32, device=dev) if kzx_out is not None else None
     _lib.call('nsgp_i8_slice_w_f64', _p(W64f), batch, M, _p(Wd), _p(wsc), st)
     _lib.call('nsgp_i8_rbf_build_f32', _p(kZ), _p(kx), n * D if kx.dim() == 3 else 0, _p(kls), _p(kos), batch, M, n, D,
-              planes, _p(Kd), _p(ksc), st)
+              planes, _p(Kd), _p(ksc), _p(K32), st)
+    if kzx_out is not None:
+        kzx_out.append(K32)
     _timed(lambda: _lib.call('nsgp_svgp_tri_gemm_colstats_i8', _p(Wd), _p(wsc), _p(Kd), _p(ksc), planes, _p(m), batch, M, n,
                              _p(A), _p(part_dot), _p(part_sq), T, 1 if p64 else 0, st), flops, 'i8')
 
 
 def svgp_project(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None, kernel_inputs=None, Kzx64=None, Lq64=None,
-                 i8_inputs=None, i8_planes=4):
+                 i8_inputs=None, i8_planes=4, i8_kzx_out=None):
     """Fused K6 forward: A = W Kzx, C = Lq^T A (triangular MFMA GEMMs) with the column statistics reduced in
     the GEMM epilogues.  W, Lq:(b,M,M) lower; Kzx:(b,M,n); m:(b,M); base:(b,).
     Returns A, C, mean = A^T m (+ the affine prior mean x w + c, `affine` = (x, w, c)), var = base + base_add +
@@ -703,7 +707,8 @@ def svgp_project(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None, kern
         part = (torch.zeros if ((T64 != T32 and not p64) or (i8 and p64)) else torch.empty)(
             (3, batch, max(T, 1), n), dtype=torch.float64 if p64 else ref.dtype, device=ref.device)
         if i8:
-            _project_a_i8(W64f, kZ, kx, kls, kos, m, A, part[0], part[1], T, p64, 5 if i8_planes == 5 else 4, flops)
+            _project_a_i8(W64f, kZ, kx, kls, kos, m, A, part[0], part[1], T, p64, 5 if i8_planes == 5 else 4, flops,
+                          kzx_out=i8_kzx_out)
         elif b64 and p64:
             _timed(lambda: _lib.call('nsgp_svgp_tri_gemm_colstats_f64acc_b64', _p(W64f), _p(Kzx64), _p(m), batch, M, n, _p(A),
                                      _p(part[0]), _p(part[1]), T, st), flops, 'f64acc')
@@ -742,7 +747,8 @@ def svgp_project(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None, kern
     return A, C, mean, var
 
 
-def svgp_project_bf16(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None, kernel_inputs=None, i8_inputs=None):
+def svgp_project_bf16(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None, kernel_inputs=None, i8_inputs=None,
+                      i8_kzx_out=None):
     """BASELINE configs[4]'s "bf16 forward": the forward projections of a float32 SVGP layer with bf16 matrix-core products
     (bf16 operands, float32 accumulation, float32 A / C; csrc/gemm_bf16.hip), column statistics in the epilogues.
 
@@ -794,7 +800,8 @@ def svgp_project_bf16(W, Kzx, Lq, m, base, base_add=0.0, affine=None, W64f=None,
         W = _c(W)
         if use_i8:
             kZ, kx, kls, kos = i8_inputs
-            _project_a_i8(_c(W64f), _c(kZ), _c(kx), _c(kls), _c(kos.reshape(-1)), m, A, part[0], part[1], Tp, False, 4, flops)
+            _project_a_i8(_c(W64f), _c(kZ), _c(kx), _c(kls), _c(kos.reshape(-1)), m, A, part[0], part[1], Tp, False, 4, flops,
+                          kzx_out=i8_kzx_out)
         elif W64f is not None:
             _timed(lambda: _lib.call('nsgp_svgp_tri_gemm_colstats_f64acc', _p(_c(W64f)), _p(Kzx), _p(m), batch, M, n, _p(A),
                                      _p(part[0]), _p(part[1]), Tp, st), flops, 'f64acc')

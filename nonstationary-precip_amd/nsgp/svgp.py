@@ -214,16 +214,22 @@ class SVGPLayerFn(torch.autograd.Function):
         elif var64:
             Lq64 = ops.cast(Lq.detach(), torch.float64)
         Kzx = None if (fuse or Kzx64 is not None or use_i8) else ops.rbf_build(Z, x, ls, os_)           # (b,M,n)
+        # int8 path: the plane-build kernel also writes the float32 Kzx the BACKWARD needs (Wbar = tril(Abar Kzx^T)) when there
+        # is going to be one -- its own build launch (28 us at the headline's last layer) disappears
+        kzx_keep = [] if (use_i8 and any(ctx.needs_input_grad)) else None
         if x.dtype == torch.float32 and fp in ('bf16', 'bf16_all') and Z.shape[-2] % 8 == 0:
             # BASELINE configs[4]'s "bf16 forward": C = Lq^T A on the bf16 matrix cores; 'bf16_all' also A = W Kzx
             A, C, mean, var = ops.svgp_project_bf16(W, Kzx, Lq, m, os_, base_add=VAR_JITTER, affine=affine, W64f=W64f,
                                                     kernel_inputs=(Z, x, ls, os_) if fp == 'bf16_all' else None,
-                                                    i8_inputs=(Z, x, ls, os_) if (use_i8 and fp == 'bf16') else None)
+                                                    i8_inputs=(Z, x, ls, os_) if (use_i8 and fp == 'bf16') else None,
+                                                    i8_kzx_out=kzx_keep if (use_i8 and fp == 'bf16') else None)
         else:
             A, C, mean, var = ops.svgp_project(W, Kzx, Lq, m, os_, base_add=VAR_JITTER, affine=affine, W64f=W64f,
                                                kernel_inputs=(Z, x, ls, os_) if fuse else None, Kzx64=Kzx64, Lq64=Lq64,
                                                i8_inputs=(Z, x, ls, os_) if use_i8 else None,
-                                               i8_planes=5 if kzx_f64 else 4)      # 2 GEMMs
+                                               i8_planes=5 if kzx_f64 else 4, i8_kzx_out=kzx_keep)      # 2 GEMMs
+        if kzx_keep:
+            Kzx = kzx_keep[0]
         ctx.save_for_backward(x, Z, ls, os_, m, Lq, W, Kzx, A, C, mean_w, mean_c)
         ctx.w_dtype = W64.dtype
         return mean, var

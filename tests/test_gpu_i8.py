@@ -107,3 +107,29 @@ def test_model_level_switch_and_backward():
     assert measured('var i8 vs f64acc', res[True][1], res[False][1], rtol=0.0, atol=2e-4 * float(res[False][1].abs().max()))
     for a, r in zip(res[True][2], res[False][2]):
         assert float((a - r).abs().max()) < 2e-3 * float(r.abs().max()) + 1e-6
+
+
+def test_plane_build_kernel_also_writes_the_float32_kzx_the_backward_reads():
+    """nsgp_i8_rbf_build_f32(..., Kzx_f32): the float32 Kzx rounded from the float64 values the digits are cut from -- equal to
+    the float64 oracle kernel rounded to float32, to one float32 ulp (the kernel's own exp is good to ~1 ulp of float64).  The
+    layer keeps it for its backward pass (Wbar = tril(Abar Kzx^T)) instead of launching a float32 build there; the gradients of
+    that path are held to the oracle by test_model_level_switch_and_backward above."""
+    import torch
+    from nsgp import _lib, ops
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    g = torch.Generator().manual_seed(4)
+    b, M, n, D = 2, 200, 333, 3
+    Z, x = torch.randn(b, M, D, generator=g), torch.randn(n, D, generator=g)
+    ls, os_ = torch.rand(b, D, generator=g) + 0.6, torch.rand(b, generator=g) + 0.5
+    lib = _lib.load()
+    dZ, dx, dls, dos = Z.cuda(), x.cuda(), ls.cuda(), os_.cuda()
+    Kd = torch.empty(int(lib.nsgp_i8_k_planes_bytes(b, M, n, 4)), dtype=torch.uint8, device='cuda')
+    ksc = torch.empty(b, dtype=torch.float64, device='cuda')
+    K32 = torch.full((b, M, n), float('nan'), device='cuda')
+    _lib.call('nsgp_i8_rbf_build_f32', ops._p(dZ), ops._p(dx), 0, ops._p(dls), ops._p(dos), b, M, n, D, 4, ops._p(Kd), ops._p(ksc),
+              ops._p(K32), ops._stream())
+    d2 = (((Z.double().unsqueeze(2) - x.double().unsqueeze(0).unsqueeze(1)) / ls.double().reshape(b, 1, 1, D)) ** 2).sum(-1)
+    ref = (os_.double().reshape(b, 1, 1) * torch.exp(-0.5 * d2)).float()
+    assert torch.isfinite(K32).all()
+    assert float((K32.cpu() - ref).abs().max()) <= 1.2e-7 * float(ref.abs().max())
