@@ -7,8 +7,9 @@
 
 Workload (BASELINE B4): DeepGP(num_layers=1) = hidden 3->2 + last 2->1, M=1024 inducing,
 S=10 likelihood samples, minibatch B=4096 of a synthetic N=100,000 spatio-temporal grid
-(100 months x 1,000 cells, time-major, z-scored), float32 with float64 Kzz Cholesky and a float64-accumulated
-whitened projection (settings.whiten_matmul_f64: the reference's float64 solve), Adam lr 0.01.
+(100 months x 1,000 cells, time-major, z-scored), float32 with float64 Kzz Cholesky and the whitened projection
+A = L^-1 Kzx as an exact int8 digit-plane product (settings.whiten_matmul_i8; better than the float64-accumulated product it
+replaces, which stands in for the reference's float64 solve), Adam lr 0.01.
 One step = forward + ELBO + backward + (gradient all-reduce) + Adam update on one 4096-row minibatch that
 is already resident in HBM.  With N > 1 (data parallel, nsgp/dist.py) the default is SURVEY 8e's split: ONE
 4096-row minibatch is shared by the N ranks (4096/N rows each; `"scaling": "strong"`, value = iterations/s);
@@ -16,7 +17,10 @@ is already resident in HBM.  With N > 1 (data parallel, nsgp/dist.py) the defaul
 ranks' objectives sum to the single-process ELBO of the global minibatch and the flat gradient bucket is summed
 with one RCCL all-reduce.
 
-Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field definitions).
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field definitions).  `dtype` "f32" names the arithmetic of the
+dominant kernels and of every stored tensor of the layers; `roofline` prices the float32 GEMM family against the data-sheet
+157.3 TFLOP/s and also reports what a register-only MFMA loop sustains on the box at hand (`sustained_mfma_measured`);
+`f64acc_projection` / `i8_projection` are the same objects for the float64-accumulating and the int8 products of the step.
 """
 import argparse
 import json
