@@ -4,7 +4,7 @@
 of panel_body2) and prints the median cycles per phase over the panels of one factorisation.
 
     make -C nonstationary-precip_amd/csrc stamps
-    python tools/probes/potrf_stamps.py [N] [float32|float64]
+    python tools/probes/potrf_stamps.py [N] [float32|float64] [batch]      (batch > 1 also prints a per-panel table)
     NSGP_LIB=tools/probes/_bin/libnsgp_stamps_blk0.so python tools/probes/potrf_stamps.py      # one pivot at a time
 """
 import ctypes
@@ -25,6 +25,7 @@ PHASES = ['load+stage', 'U0 (prev rank-64 on cols 0..15)', 'factor 0', 'barrier'
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     dt = getattr(torch, sys.argv[2]) if len(sys.argv) > 2 else torch.float64
+    batch = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     _lib.load()
     raw = ctypes.CDLL(_lib.LIB_PATH)
     raw.nsgp_debug_potrf_stamps.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
@@ -34,6 +35,8 @@ def main():
     g = torch.Generator().manual_seed(0)
     X = torch.randn(n, n + 8, generator=g, dtype=torch.float64)
     K = (X @ X.T / n + torch.eye(n, dtype=torch.float64)).to(dt).cuda()
+    if batch > 1:
+        K = K.unsqueeze(0).repeat(batch, 1, 1).contiguous()
     for _ in range(3):
         L, info = ops.potrf(K.clone())
     torch.cuda.synchronize()
@@ -47,6 +50,10 @@ def main():
     assert int(info.max()) == 0
     full = buf.cpu().numpy().view(np.uint64).reshape(cap, 64)
     full = full[full[:, 15] != 0].astype(np.float64)
+    if batch > 1:
+        print('per panel (workgroup 0 of matrix 0): whole-workgroup cycles, load+stage cycles')
+        for i, r in enumerate(full):
+            print(f'    panel {i:3d}: {r[15] - r[0]:8.0f} {r[1] - r[0]:8.0f}')
     full = full[1:-1] if len(full) > 4 else full
     a = full[:, :16]
     d = np.diff(a, axis=1)
